@@ -1,0 +1,137 @@
+// Instance binning: offsets of each Gaussian's tile instances, (tile|depth)
+// key emission and per-tile ranges of the sorted list.  Integer work, HBM
+// bound.  Results are those of the reference's InclusiveSum +
+// duplicateWithKeys + identifyTileRanges
+// (cuda_rasterizer/rasterizer_impl.cu:70-138,277-318); the schedule is not:
+// the prefix sum is two-level (per-256-Gaussian block sums come out of the
+// preprocess kernel, one workgroup scans them, the emission kernel rescans
+// inside its block), and keys are emitted by whole waves into contiguous
+// output runs instead of by one serial loop per Gaussian.
+#include "ngs_common.h"
+
+#define SCAN_THREADS 1024
+
+// Exclusive scan of the per-block tile counts by a single workgroup.  Thread t
+// owns a contiguous run of ceil(n/1024) entries.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, const uint32_t* __restrict__ in,
+                                                                        uint32_t* __restrict__ out,
+                                                                        uint32_t* __restrict__ misc)
+{
+    __shared__ uint32_t wave_tot[SCAN_THREADS / 64];
+    const int per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = threadIdx.x * per;
+    const int hi = min(n, lo + per);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += in[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_u32(s, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        const uint32_t t = wave_tot[w];
+        if (w < wave) base += t;
+        total += t;
+    }
+    uint32_t run = base + incl - s;
+    for (int i = lo; i < hi; i++) {
+        const uint32_t v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) misc[0] = total;
+}
+
+// One workgroup per 256 Gaussians (the same blocks as the preprocess kernel).
+// Each wave owns 64 consecutive Gaussians, whose instances occupy one
+// contiguous run of the output; the wave walks that run 64 entries at a time,
+// each lane locating its Gaussian by binary search over the wave's prefix sums,
+// so key/value stores are fully coalesced whatever the footprint sizes are.
+__global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const uint2* __restrict__ rect,
+                                                                    const float* __restrict__ depth,
+                                                                    const uint32_t* __restrict__ tiles,
+                                                                    const uint32_t* __restrict__ block_offs,
+                                                                    int grid_x, uint64_t* __restrict__ keys,
+                                                                    uint32_t* __restrict__ vals)
+{
+    __shared__ uint32_t s_incl[NGS_GAUSS_BLOCK];  // per wave: inclusive prefix of tiles within the wave
+    __shared__ uint2 s_rect[NGS_GAUSS_BLOCK];
+    __shared__ uint32_t s_depth[NGS_GAUSS_BLOCK];
+    __shared__ uint32_t s_wave_tot[NGS_GAUSS_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * NGS_GAUSS_BLOCK + tid;
+    uint32_t cnt = 0;
+    if (idx < P) {
+        cnt = tiles[idx];
+        if (cnt) {
+            s_rect[tid] = rect[idx];
+            s_depth[tid] = __float_as_uint(depth[idx]);
+        }
+    }
+    const uint32_t incl = wave_incl_scan_u32(cnt, lane);
+    s_incl[tid] = incl;
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = block_offs[blockIdx.x];
+    for (int w = 0; w < wave; w++) wave_base += s_wave_tot[w];
+    const uint32_t wave_total = s_wave_tot[wave];
+    const uint32_t* incl_w = s_incl + wave * 64;
+    for (uint32_t k = lane; k < wave_total; k += 64) {
+        // smallest j with incl_w[j] > k
+        int lo = 0, hi = 63;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (incl_w[mid] > k) hi = mid; else lo = mid + 1;
+        }
+        const int j = lo;
+        const uint32_t local = k - (j ? incl_w[j - 1] : 0u);
+        const uint2 r = s_rect[wave * 64 + j];
+        const uint32_t x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu;
+        const uint32_t w = x1 - x0;
+        const uint32_t ty = y0 + local / w, tx = x0 + local % w;
+        const uint64_t key = ((uint64_t)(ty * (uint32_t)grid_x + tx) << 32) | s_depth[wave * 64 + j];
+        keys[(size_t)wave_base + k] = key;
+        vals[(size_t)wave_base + k] = (uint32_t)(blockIdx.x * NGS_GAUSS_BLOCK + wave * 64 + j);
+    }
+}
+
+// rasterizer_impl.cu:116-138; `ranges` was zeroed by the caller.
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t L, const uint64_t* __restrict__ keys,
+                                                          uint2* __restrict__ ranges)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) {
+        ranges[cur].x = 0;
+    } else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (cur != prev) {
+            ranges[prev].y = (uint32_t)idx;
+            ranges[cur].x = (uint32_t)idx;
+        }
+    }
+    if (idx == L - 1) ranges[cur].y = (uint32_t)L;
+}
+
+void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* block_sums, uint32_t* block_offs,
+                                uint32_t* misc)
+{
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblocks, block_sums, block_offs,
+                       misc);
+}
+
+void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const float* depth, const uint32_t* tiles,
+                          const uint32_t* block_offs, int grid_x, uint64_t* keys, uint32_t* vals)
+{
+    const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, rect, depth, tiles, block_offs,
+                       grid_x, keys, vals);
+}
+
+void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint64_t* keys, int T, uint2* ranges)
+{
+    (void)hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s);
+    if (R > 0)
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);
+}

@@ -1,0 +1,235 @@
+// extern "C" entry points of libngs_rasterizer.so (declared in
+// include/ngs_rasterizer.h): carve the caller's scratch buffers, run the stages
+// in order on the caller's stream, report errors by return code.  Pipeline
+// order follows cuda_rasterizer/rasterizer_impl.cu:198-434 of the reference.
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ngs_rasterizer.h"
+#include "ngs_common.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* what, const char* detail)
+{
+    snprintf(g_err, sizeof g_err, "%s%s%s", what, detail ? ": " : "", detail ? detail : "");
+    return 1;
+}
+
+#define NGS_HIP(call)                                                   \
+    do {                                                                \
+        hipError_t e_ = (call);                                         \
+        if (e_ != hipSuccess) return fail(#call, hipGetErrorString(e_)); \
+    } while (0)
+
+// After each stage: launch errors always; in debug mode also a stream sync, as
+// the reference's CHECK_CUDA does (auxiliary.h:166-173).
+#define NGS_STAGE(name)                                                                \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(st);                  \
+        if (e_ != hipSuccess) return fail("stage " name, hipGetErrorString(e_));       \
+    } while (0)
+
+// rasterizer_impl.cu:35-50
+static uint32_t higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+static NgsCamera make_camera(int W, int H, float tanx, float tany, const float* view, const float* proj,
+                             const float* campos)
+{
+    NgsCamera c;
+    c.view = view; c.proj = proj; c.campos = campos;
+    c.tan_fovx = tanx; c.tan_fovy = tany;
+    c.focal_y = H / (2.0f * tany);
+    c.focal_x = W / (2.0f * tanx);
+    c.W = W; c.H = H;
+    c.grid_x = (W + NGS_TILE_W - 1) / NGS_TILE_W;
+    c.grid_y = (H + NGS_TILE_H - 1) / NGS_TILE_H;
+    return c;
+}
+
+extern "C" const char* ngs_last_error(void) { return g_err; }
+
+extern "C" size_t ngs_required_geometry_bytes(int P) { return ngs_geom_layout((size_t)(P > 0 ? P : 0)).total; }
+extern "C" size_t ngs_required_binning_bytes(long long R) { return ngs_bin_layout((size_t)(R > 0 ? R : 0)).total; }
+extern "C" size_t ngs_required_image_bytes(int W, int H) { return ngs_image_layout(W, H).total; }
+
+extern "C" int ngs_state_layout(int P, long long R, int W, int H, size_t* geometry, size_t* binning, size_t* image)
+{
+    if (geometry) {
+        const GeomLayout g = ngs_geom_layout((size_t)P);
+        const size_t v[12] = {g.g0, g.g1, g.g2, g.depth, g.rect, g.tiles, g.radii, g.clamped, g.block_sums,
+                              g.block_offs, g.misc, g.acc};
+        memcpy(geometry, v, sizeof v);
+    }
+    if (binning) {
+        const BinLayout b = ngs_bin_layout((size_t)R);
+        binning[0] = b.keys[0];
+        binning[1] = b.vals[0];
+    }
+    if (image) {
+        const ImageLayout i = ngs_image_layout(W, H);
+        image[0] = i.final_T; image[1] = i.n_contrib; image[2] = i.ranges;
+    }
+    return 0;
+}
+
+extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
+                                     void* binning_ctx, ngs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                                     const float* background, int width, int height, const float* means3D,
+                                     const float* shs, const float* colors_precomp, const float* opacities,
+                                     const float* scales, float scale_modifier, const float* rotations,
+                                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                     const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                                     float* out_color, int* radii, int debug, void* stream, int* num_rendered)
+{
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (num_rendered) *num_rendered = 0;
+    if (P < 0 || width <= 0 || height <= 0) return fail("ngs_rasterize_forward", "bad sizes");
+    if (P == 0) return 0;
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail("ngs_rasterize_forward", "missing allocator");
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !background || !out_color)
+        return fail("ngs_rasterize_forward", "missing required pointer");
+    if (!colors_precomp && (!shs || !cam_pos)) return fail("ngs_rasterize_forward", "need shs+cam_pos or colors_precomp");
+    if (!colors_precomp && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
+        return fail("ngs_rasterize_forward", "SH degree does not fit the coefficient count");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail("ngs_rasterize_forward", "need scales+rotations or cov3D_precomp");
+    const NgsCamera cam = make_camera(width, height, tan_fovx, tan_fovy, viewmatrix, projmatrix, cam_pos);
+    if (cam.grid_x > 65535 || cam.grid_y > 65535) return fail("ngs_rasterize_forward", "image too large");
+
+    const GeomLayout gl = ngs_geom_layout((size_t)P);
+    char* gb = geometry_alloc(geometry_ctx, gl.total);
+    if (!gb) return fail("ngs_rasterize_forward", "geometry allocator returned NULL");
+    gb = ngs_align_ptr(gb);
+    const ImageLayout il = ngs_image_layout(width, height);
+    char* ib = image_alloc(image_ctx, il.total);
+    if (!ib) return fail("ngs_rasterize_forward", "image allocator returned NULL");
+    ib = ngs_align_ptr(ib);
+
+    float4* g0 = (float4*)(gb + gl.g0);
+    float4* g1 = (float4*)(gb + gl.g1);
+    float* g2 = (float*)(gb + gl.g2);
+    float* depth = (float*)(gb + gl.depth);
+    uint2* rect = (uint2*)(gb + gl.rect);
+    uint32_t* tiles = (uint32_t*)(gb + gl.tiles);
+    uint8_t* clamped = (uint8_t*)(gb + gl.clamped);
+    uint32_t* block_sums = (uint32_t*)(gb + gl.block_sums);
+    uint32_t* block_offs = (uint32_t*)(gb + gl.block_offs);
+    uint32_t* misc = (uint32_t*)(gb + gl.misc);
+    if (!radii) radii = (int*)(gb + gl.radii);
+    const int nblocks = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+
+    NGS_HIP(hipMemsetAsync(misc, 0, 32, st));
+    ngs_launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+                              colors_precomp, cam, prefiltered, radii, g0, g1, g2, depth, rect, tiles, clamped,
+                              block_sums, misc);
+    NGS_STAGE("preprocess");
+    ngs_launch_scan_block_sums(st, nblocks, block_sums, block_offs, misc);
+    NGS_STAGE("scan");
+
+    // The instance count sizes the binning buffer: one blocking 8-byte read-back.
+    uint32_t host_misc[2] = {0, 0};
+    NGS_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, st));
+    NGS_HIP(hipStreamSynchronize(st));
+    if (host_misc[1] & 1u) return fail("ngs_rasterize_forward", "Point is filtered although prefiltered is set. This shouldn't happen!");
+    if (host_misc[0] > 0x7fffffffu) return fail("ngs_rasterize_forward", "more than 2^31-1 tile instances");
+    const int64_t R = (int64_t)host_misc[0];
+    if (num_rendered) *num_rendered = (int)R;
+
+    const BinLayout bl = ngs_bin_layout((size_t)R);
+    char* bb = binning_alloc(binning_ctx, bl.total);
+    if (!bb) return fail("ngs_rasterize_forward", "binning allocator returned NULL");
+    bb = ngs_align_ptr(bb);
+    uint64_t* keys[2] = {(uint64_t*)(bb + bl.keys[0]), (uint64_t*)(bb + bl.keys[1])};
+    uint32_t* vals[2] = {(uint32_t*)(bb + bl.vals[0]), (uint32_t*)(bb + bl.vals[1])};
+    uint32_t* hist = (uint32_t*)(bb + bl.hist);
+    uint32_t* totals = (uint32_t*)(bb + bl.totals);
+
+    const int T = cam.grid_x * cam.grid_y;
+    const int end_bit = 32 + (int)higher_msb((uint32_t)T);
+    const int in_buf = ngs_sort_input_buffer(end_bit);
+    if (R > 0) {
+        ngs_launch_duplicate(st, P, rect, depth, tiles, block_offs, cam.grid_x, keys[in_buf], vals[in_buf]);
+        NGS_STAGE("duplicateWithKeys");
+        ngs_launch_sort_pairs(st, R, keys, vals, hist, totals, end_bit);
+        NGS_STAGE("sort");
+    }
+    uint2* ranges = (uint2*)(ib + il.ranges);
+    ngs_launch_tile_ranges(st, R, keys[0], T, ranges);
+    NGS_STAGE("identifyTileRanges");
+    ngs_launch_render_fwd(st, cam, ranges, vals[0], g0, g1, g2, background, (float*)(ib + il.final_T),
+                          (uint32_t*)(ib + il.n_contrib), out_color);
+    NGS_STAGE("render");
+    return 0;
+}
+
+extern "C" int ngs_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                                      const float* means3D, const float* shs, const float* colors_precomp,
+                                      const float* scales, float scale_modifier, const float* rotations,
+                                      const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                      const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                                      char* geom_buffer, char* binning_buffer, char* image_buffer,
+                                      const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                      float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                                      float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    (void)colors_precomp;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail("ngs_rasterize_backward", "bad sizes");
+    if (P == 0) return 0;
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail("ngs_rasterize_backward", "missing state buffer");
+    if (!means3D || !viewmatrix || !projmatrix || !background || !dL_dpix || !dL_dmean2D || !dL_dopacity ||
+        !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+        return fail("ngs_rasterize_backward", "missing required pointer");
+    if (shs && (!dL_dsh || !campos)) return fail("ngs_rasterize_backward", "shs given without dL_dsh / campos");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail("ngs_rasterize_backward", "need scales+rotations or cov3D_precomp");
+    const NgsCamera cam = make_camera(width, height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos);
+    const GeomLayout gl = ngs_geom_layout((size_t)P);
+    const BinLayout bl = ngs_bin_layout((size_t)R);
+    const ImageLayout il = ngs_image_layout(width, height);
+    char* gb = ngs_align_ptr(geom_buffer);
+    char* bb = ngs_align_ptr(binning_buffer);
+    char* ib = ngs_align_ptr(image_buffer);
+    if (!radii) radii = (const int*)(gb + gl.radii);
+    float* acc = (float*)(gb + gl.acc);
+
+    NGS_HIP(hipMemsetAsync(acc, 0, (size_t)P * NGS_ACC_STRIDE * sizeof(float), st));
+    ngs_launch_render_bwd(st, cam, (const uint2*)(ib + il.ranges), (const uint32_t*)(bb + bl.vals[0]),
+                          (const float4*)(gb + gl.g0), (const float4*)(gb + gl.g1), (const float*)(gb + gl.g2),
+                          background, (const float*)(ib + il.final_T), (const uint32_t*)(ib + il.n_contrib), dL_dpix,
+                          acc);
+    NGS_STAGE("render backward");
+    // scales == NULL (precomputed covariance) skips the scale/rotation gradients, shs == NULL the SH ones,
+    // as in the reference (backward.cu:390-395).
+    ngs_launch_preprocess_bwd(st, P, D, M, means3D, radii, shs, (const uint8_t*)(gb + gl.clamped),
+                              cov3D_precomp ? nullptr : scales, rotations, scale_modifier, cov3D_precomp, cam, acc,
+                              dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                              dL_drot);
+    NGS_STAGE("preprocess backward");
+    return 0;
+}
+
+extern "C" int ngs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                unsigned char* present, void* stream)
+{
+    g_err[0] = 0;
+    (void)projmatrix;
+    if (P < 0) return fail("ngs_mark_visible", "bad size");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail("ngs_mark_visible", "missing required pointer");
+    ngs_launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("stage checkFrustum", hipGetErrorString(e));
+    return 0;
+}

@@ -1,0 +1,327 @@
+// Shared declarations for the gfx950 rasterizer library: state layouts carved
+// out of the three caller-owned scratch buffers, launch prototypes of every
+// stage, and the device math both per-Gaussian kernels (forward and backward)
+// must evaluate identically.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define NGS_TILE_W 16
+#define NGS_TILE_H 16
+#define NGS_TILE_PIX 256
+#define NGS_GAUSS_BLOCK 256  // Gaussians per workgroup in the per-Gaussian kernels; also the scan granule
+#define NGS_ACC_STRIDE 16    // floats per Gaussian in the 64-byte gradient accumulator rows
+#define NGS_ALIGN 256
+
+// Slots of one accumulator row filled by the backward compositing kernel.
+enum { ACC_DX = 0, ACC_DY, ACC_CON_A, ACC_CON_B, ACC_CON_C, ACC_OPAC, ACC_R, ACC_G, ACC_B, ACC_USED };
+
+// ---------------------------------------------------------------------------
+// Scratch-buffer layouts.  Offsets are relative to the 256-byte aligned base of
+// the buffer the caller's allocator returned; forward and backward compute the
+// same offsets from (P), (R) and (W,H), the way the reference re-carves its
+// chunks (cuda_rasterizer/rasterizer_impl.cu:155-194,371-373).
+// ---------------------------------------------------------------------------
+struct GeomLayout {
+    size_t g0;         // float4[P]  {pixel x, pixel y, conic a, conic b}
+    size_t g1;         // float4[P]  {conic c, opacity, red, green}
+    size_t g2;         // float [P]  {blue}
+    size_t depth;      // float [P]  view-space z
+    size_t rect;       // uint2 [P]  packed tile rectangle: x = min.x | max.x<<16, y = min.y | max.y<<16
+    size_t tiles;      // u32   [P]  tiles touched
+    size_t radii;      // i32   [P]  internal radii when the caller passes none
+    size_t clamped;    // u8    [P]  bit ch set when colour channel ch was clamped at 0
+    size_t block_sums; // u32   [ceil(P/256)] tiles touched per 256-Gaussian block
+    size_t block_offs; // u32   [ceil(P/256)] exclusive prefix of block_sums
+    size_t misc;       // u32   [8]  [0] total instances R, [1] error flags
+    size_t acc;        // float [P][16] gradient accumulator rows (backward)
+    size_t total;
+};
+
+struct ImageLayout {
+    size_t final_T;   // float[T*256] tile-major: pixel (tile, ly*16+lx)
+    size_t n_contrib; // u32  [T*256] tile-major
+    size_t ranges;    // uint2[T]
+    size_t total;
+};
+
+struct BinLayout {
+    size_t keys[2];  // u64[R] ping/pong; keys[0] holds the sorted keys when the sort is done
+    size_t vals[2];  // u32[R] ping/pong; vals[0] is the sorted point list
+    size_t hist;     // u32[256 * sort_blocks] digit-major per-block histogram
+    size_t totals;   // u32[256] per-digit totals
+    size_t total;
+};
+
+static inline size_t ngs_align_up(size_t v) { return (v + NGS_ALIGN - 1) & ~(size_t)(NGS_ALIGN - 1); }
+
+#define NGS_SORT_THREADS 256
+#define NGS_SORT_ITEMS 8
+#define NGS_SORT_TILE (NGS_SORT_THREADS * NGS_SORT_ITEMS)
+
+static inline GeomLayout ngs_geom_layout(size_t P)
+{
+    GeomLayout l;
+    size_t o = 0, nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    l.g0 = o; o = ngs_align_up(o + P * 16);
+    l.g1 = o; o = ngs_align_up(o + P * 16);
+    l.g2 = o; o = ngs_align_up(o + P * 4);
+    l.depth = o; o = ngs_align_up(o + P * 4);
+    l.rect = o; o = ngs_align_up(o + P * 8);
+    l.tiles = o; o = ngs_align_up(o + P * 4);
+    l.radii = o; o = ngs_align_up(o + P * 4);
+    l.clamped = o; o = ngs_align_up(o + P);
+    l.block_sums = o; o = ngs_align_up(o + nb * 4);
+    l.block_offs = o; o = ngs_align_up(o + nb * 4);
+    l.misc = o; o = ngs_align_up(o + 32);
+    l.acc = o; o = ngs_align_up(o + P * NGS_ACC_STRIDE * 4);
+    l.total = o + NGS_ALIGN;
+    return l;
+}
+
+static inline ImageLayout ngs_image_layout(int W, int H)
+{
+    ImageLayout l;
+    size_t T = (size_t)((W + NGS_TILE_W - 1) / NGS_TILE_W) * ((H + NGS_TILE_H - 1) / NGS_TILE_H);
+    size_t o = 0;
+    l.final_T = o; o = ngs_align_up(o + T * NGS_TILE_PIX * 4);
+    l.n_contrib = o; o = ngs_align_up(o + T * NGS_TILE_PIX * 4);
+    l.ranges = o; o = ngs_align_up(o + T * 8);
+    l.total = o + NGS_ALIGN;
+    return l;
+}
+
+static inline BinLayout ngs_bin_layout(size_t R)
+{
+    BinLayout l;
+    size_t o = 0, nb = (R + NGS_SORT_TILE - 1) / NGS_SORT_TILE;
+    l.keys[0] = o; o = ngs_align_up(o + R * 8);
+    l.keys[1] = o; o = ngs_align_up(o + R * 8);
+    l.vals[0] = o; o = ngs_align_up(o + R * 4);
+    l.vals[1] = o; o = ngs_align_up(o + R * 4);
+    l.hist = o; o = ngs_align_up(o + nb * 256 * 4);
+    l.totals = o; o = ngs_align_up(o + 256 * 4);
+    l.total = o + NGS_ALIGN;
+    return l;
+}
+
+static inline char* ngs_align_ptr(char* p)
+{
+    return (char*)(((uintptr_t)p + NGS_ALIGN - 1) & ~(uintptr_t)(NGS_ALIGN - 1));
+}
+
+// Per-call camera constants.  The scalars travel to kernels by value; the
+// matrices stay in device memory (the caller's tensors) and are read through
+// wave-uniform scalar loads, so no host copy or synchronisation is needed.
+struct NgsCamera {
+    const float* view;    // 16 floats, device
+    const float* proj;    // 16 floats, device
+    const float* campos;  // 3 floats, device
+    float tan_fovx, tan_fovy, focal_x, focal_y;
+    int W, H, grid_x, grid_y;
+};
+
+// ---------------------------------------------------------------------------
+// Stage launchers (each defined in the .hip file named in the comment).
+// ---------------------------------------------------------------------------
+// preprocess_fwd.hip
+void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* means, const float* scales, float mod,
+                               const float* rots, const float* opac, const float* shs, const float* cov_pre,
+                               const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* g0,
+                               float4* g1, float* g2, float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
+                               uint32_t* block_sums, uint32_t* misc);
+void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const float* view, uint8_t* present);
+// binning.hip
+void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* block_sums, uint32_t* block_offs,
+                                uint32_t* misc);
+void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const float* depth, const uint32_t* tiles,
+                          const uint32_t* block_offs, int grid_x, uint64_t* keys, uint32_t* vals);
+void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint64_t* keys, int T, uint2* ranges);
+// radix_sort.hip: stable LSD sort on key bits [0,end_bit); result in keys[0]/vals[0]; returns the buffer index
+// (0 or 1) the unsorted input must have been written to.
+int ngs_sort_input_buffer(int end_bit);
+void ngs_launch_sort_pairs(hipStream_t s, int64_t R, uint64_t* const keys[2], uint32_t* const vals[2], uint32_t* hist,
+                           uint32_t* totals, int end_bit);
+// render_fwd.hip
+void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
+                           const float4* g0, const float4* g1, const float* g2, const float* bg, float* final_T,
+                           uint32_t* n_contrib, float* out_color);
+// render_bwd.hip
+void ngs_launch_render_bwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
+                           const float4* g0, const float4* g1, const float* g2, const float* bg, const float* final_T,
+                           const uint32_t* n_contrib, const float* dL_dpix, float* acc);
+// preprocess_bwd.hip
+void ngs_launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* means, const int* radii,
+                               const float* shs, const uint8_t* clamped, const float* scales, const float* rots,
+                               float mod, const float* cov_pre, const NgsCamera& cam, const float* acc,
+                               float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------
+// Device math shared by preprocess forward and backward.  Matrices are stored
+// c[col][row] and multiplied in the order of the reference's vendored GLM
+// (third_party/glm/glm/detail/type_mat3x3.inl:486-519) so that forward and
+// backward, and the CPU checker, see bit-identical covariance values.  These
+// translation units are compiled with -ffp-contract=off.
+// ---------------------------------------------------------------------------
+struct Mat3 { float c[3][3]; };
+
+__device__ __forceinline__ Mat3 m3_mul(const Mat3& a, const Mat3& b)
+{
+    Mat3 r;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            r.c[j][i] = a.c[0][i] * b.c[j][0] + a.c[1][i] * b.c[j][1] + a.c[2][i] * b.c[j][2];
+    return r;
+}
+
+__device__ __forceinline__ Mat3 m3_tr(const Mat3& a)
+{
+    Mat3 r;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) r.c[j][i] = a.c[i][j];
+    return r;
+}
+
+__device__ __forceinline__ Mat3 m3_diag(float a, float b, float c)
+{
+    Mat3 r;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) r.c[j][i] = 0.0f;
+    r.c[0][0] = a; r.c[1][1] = b; r.c[2][2] = c;
+    return r;
+}
+
+// Rotation matrix of quaternion (r,x,y,z) used as given (cuda_rasterizer/forward.cu:126-138).
+__device__ __forceinline__ Mat3 m3_from_quat(float r, float x, float y, float z)
+{
+    Mat3 R;
+    R.c[0][0] = 1.f - 2.f * (y * y + z * z); R.c[0][1] = 2.f * (x * y - r * z); R.c[0][2] = 2.f * (x * z + r * y);
+    R.c[1][0] = 2.f * (x * y + r * z); R.c[1][1] = 1.f - 2.f * (x * x + z * z); R.c[1][2] = 2.f * (y * z - r * x);
+    R.c[2][0] = 2.f * (x * z - r * y); R.c[2][1] = 2.f * (y * z + r * x); R.c[2][2] = 1.f - 2.f * (x * x + y * y);
+    return R;
+}
+
+// World covariance (xx,xy,xz,yy,yz,zz) from scale and quaternion (cuda_rasterizer/forward.cu:118-152).
+__device__ __forceinline__ void cov3d_from_scale_rot(float sx, float sy, float sz, float mod, float qr, float qx,
+                                                     float qy, float qz, float out[6])
+{
+    Mat3 M = m3_mul(m3_diag(mod * sx, mod * sy, mod * sz), m3_from_quat(qr, qx, qy, qz));
+    Mat3 S = m3_mul(m3_tr(M), M);
+    out[0] = S.c[0][0]; out[1] = S.c[0][1]; out[2] = S.c[0][2];
+    out[3] = S.c[1][1]; out[4] = S.c[1][2]; out[5] = S.c[2][2];
+}
+
+__device__ __forceinline__ float3 xform43(float px, float py, float pz, const float* m)
+{
+    return make_float3(m[0] * px + m[4] * py + m[8] * pz + m[12], m[1] * px + m[5] * py + m[9] * pz + m[13],
+                       m[2] * px + m[6] * py + m[10] * pz + m[14]);
+}
+
+__device__ __forceinline__ float4 xform44(float px, float py, float pz, const float* m)
+{
+    return make_float4(m[0] * px + m[4] * py + m[8] * pz + m[12], m[1] * px + m[5] * py + m[9] * pz + m[13],
+                       m[2] * px + m[6] * py + m[10] * pz + m[14], m[3] * px + m[7] * py + m[11] * pz + m[15]);
+}
+
+// Screen-space covariance and the intermediates its backward needs
+// (cuda_rasterizer/forward.cu:74-113, backward.cu:166-199).
+struct Cov2D {
+    Mat3 T, W, V;
+    float3 t;
+    float txtz, tytz, limx, limy, a, b, c;
+};
+
+__device__ __forceinline__ Cov2D cov2d_eval(float mx, float my, float mz, const NgsCamera& cam,
+                                            const float* __restrict__ vm, const float cov6[6])
+{
+    Cov2D k;
+    k.t = xform43(mx, my, mz, vm);
+    k.limx = 1.3f * cam.tan_fovx;
+    k.limy = 1.3f * cam.tan_fovy;
+    k.txtz = k.t.x / k.t.z;
+    k.tytz = k.t.y / k.t.z;
+    k.t.x = fminf(k.limx, fmaxf(-k.limx, k.txtz)) * k.t.z;
+    k.t.y = fminf(k.limy, fmaxf(-k.limy, k.tytz)) * k.t.z;
+    Mat3 J;
+    J.c[0][0] = cam.focal_x / k.t.z; J.c[0][1] = 0.0f; J.c[0][2] = -(cam.focal_x * k.t.x) / (k.t.z * k.t.z);
+    J.c[1][0] = 0.0f; J.c[1][1] = cam.focal_y / k.t.z; J.c[1][2] = -(cam.focal_y * k.t.y) / (k.t.z * k.t.z);
+    J.c[2][0] = 0.0f; J.c[2][1] = 0.0f; J.c[2][2] = 0.0f;
+    k.W.c[0][0] = vm[0]; k.W.c[0][1] = vm[4]; k.W.c[0][2] = vm[8];
+    k.W.c[1][0] = vm[1]; k.W.c[1][1] = vm[5]; k.W.c[1][2] = vm[9];
+    k.W.c[2][0] = vm[2]; k.W.c[2][1] = vm[6]; k.W.c[2][2] = vm[10];
+    k.T = m3_mul(k.W, J);
+    k.V.c[0][0] = cov6[0]; k.V.c[0][1] = cov6[1]; k.V.c[0][2] = cov6[2];
+    k.V.c[1][0] = cov6[1]; k.V.c[1][1] = cov6[3]; k.V.c[1][2] = cov6[4];
+    k.V.c[2][0] = cov6[2]; k.V.c[2][1] = cov6[4]; k.V.c[2][2] = cov6[5];
+    Mat3 cov = m3_mul(m3_mul(m3_tr(k.T), m3_tr(k.V)), k.T);
+    k.a = cov.c[0][0] + 0.3f;
+    k.b = cov.c[0][1];
+    k.c = cov.c[1][1] + 0.3f;
+    return k;
+}
+
+// Spherical-harmonics constants (cuda_rasterizer/auxiliary.h:22-39).
+#define NGS_SH_C0 0.28209479177387814f
+#define NGS_SH_C1 0.4886025119029199f
+#define NGS_SH_C2_0 1.0925484305920792f
+#define NGS_SH_C2_1 -1.0925484305920792f
+#define NGS_SH_C2_2 0.31539156525252005f
+#define NGS_SH_C2_3 -1.0925484305920792f
+#define NGS_SH_C2_4 0.5462742152960396f
+#define NGS_SH_C3_0 -0.5900435899266435f
+#define NGS_SH_C3_1 2.890611442640554f
+#define NGS_SH_C3_2 -0.4570457994644658f
+#define NGS_SH_C3_3 0.3731763325901154f
+#define NGS_SH_C3_4 -0.4570457994644658f
+#define NGS_SH_C3_5 1.445305721320277f
+#define NGS_SH_C3_6 -0.5900435899266435f
+
+__device__ __forceinline__ float3 f3_scale(float s, float3 v) { return make_float3(s * v.x, s * v.y, s * v.z); }
+__device__ __forceinline__ float3 f3_add(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 f3_sub(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float f3_dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 only.
+// Row-wise inclusive scan by DPP row shifts, then two row broadcasts.
+__device__ __forceinline__ float wave_sum_lane63(float v)
+{
+#define NGS_DPP_ADD(ctrl, rmask)                                                                               \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, \
+                                                               false))
+    NGS_DPP_ADD(0x111, 0xf);  // row_shr:1
+    NGS_DPP_ADD(0x112, 0xf);  // row_shr:2
+    NGS_DPP_ADD(0x114, 0xf);  // row_shr:4
+    NGS_DPP_ADD(0x118, 0xf);  // row_shr:8
+    NGS_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    NGS_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef NGS_DPP_ADD
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Inclusive prefix sum across the 64 lanes of a wave.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+#endif  // __HIPCC__

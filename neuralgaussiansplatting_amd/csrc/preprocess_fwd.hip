@@ -1,0 +1,153 @@
+// Per-Gaussian forward stage: near cull, projection, EWA screen-space
+// covariance, conic + radius, tile rectangle, SH -> RGB.  One lane per
+// Gaussian; outputs go to the packed SoA records the compositing kernels
+// stage into LDS.  Follows cuda_rasterizer/forward.cu:155-256 and
+// auxiliary.h:41-56,139-164 of the reference.  Built with -ffp-contract=off:
+// radii, rectangles and depth bits must equal the CPU checker's exactly.
+#include "ngs_common.h"
+
+// auxiliary.h:41-44 (double arithmetic, rounded once to float)
+__device__ __forceinline__ float ndc_to_pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// forward.cu:20-71.  `sh` points at this Gaussian's M x 3 coefficients.
+__device__ __forceinline__ float3 sh_to_rgb(int deg, const float* __restrict__ sh, float3 dir, uint32_t& clamp_bits)
+{
+    const float3* c = (const float3*)sh;
+    float3 res = f3_scale(NGS_SH_C0, c[0]);
+    if (deg > 0) {
+        const float x = dir.x, y = dir.y, z = dir.z;
+        res = f3_sub(f3_add(f3_sub(res, f3_scale(NGS_SH_C1 * y, c[1])), f3_scale(NGS_SH_C1 * z, c[2])),
+                     f3_scale(NGS_SH_C1 * x, c[3]));
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = f3_add(res, f3_scale(NGS_SH_C2_0 * xy, c[4]));
+            res = f3_add(res, f3_scale(NGS_SH_C2_1 * yz, c[5]));
+            res = f3_add(res, f3_scale(NGS_SH_C2_2 * (2.0f * zz - xx - yy), c[6]));
+            res = f3_add(res, f3_scale(NGS_SH_C2_3 * xz, c[7]));
+            res = f3_add(res, f3_scale(NGS_SH_C2_4 * (xx - yy), c[8]));
+            if (deg > 2) {
+                res = f3_add(res, f3_scale(NGS_SH_C3_0 * y * (3.0f * xx - yy), c[9]));
+                res = f3_add(res, f3_scale(NGS_SH_C3_1 * xy * z, c[10]));
+                res = f3_add(res, f3_scale(NGS_SH_C3_2 * y * (4.0f * zz - xx - yy), c[11]));
+                res = f3_add(res, f3_scale(NGS_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), c[12]));
+                res = f3_add(res, f3_scale(NGS_SH_C3_4 * x * (4.0f * zz - xx - yy), c[13]));
+                res = f3_add(res, f3_scale(NGS_SH_C3_5 * z * (xx - yy), c[14]));
+                res = f3_add(res, f3_scale(NGS_SH_C3_6 * x * (xx - 3.0f * yy), c[15]));
+            }
+        }
+    }
+    res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+    clamp_bits = (res.x < 0 ? 1u : 0u) | (res.y < 0 ? 2u : 0u) | (res.z < 0 ? 4u : 0u);
+    return make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
+}
+
+__global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
+    int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float mod,
+    const float* __restrict__ rots, const float* __restrict__ opac, const float* __restrict__ shs,
+    const float* __restrict__ cov_pre, const float* __restrict__ col_pre, const NgsCamera cam,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, int prefiltered,
+    int* __restrict__ radii, float4* __restrict__ g0, float4* __restrict__ g1, float* __restrict__ g2,
+    float* __restrict__ depth, uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint8_t* __restrict__ clamped,
+    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ misc)
+{
+    __shared__ uint32_t wave_tot[NGS_GAUSS_BLOCK / 64];
+    const int idx = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
+    uint32_t my_tiles = 0;
+    int my_radius = 0;
+    if (idx < P) {
+        const float px = means[3 * idx], py = means[3 * idx + 1], pz = means[3 * idx + 2];
+        const float3 pv = xform43(px, py, pz, view);
+        if (pv.z <= 0.2f) {
+            // The reference aborts the kernel here when `prefiltered` is set
+            // (auxiliary.h:156-160); this library raises an error flag that the
+            // host turns into an error return instead of faulting the GPU.
+            if (prefiltered) misc[1] = 1u;
+        } else {
+            const float4 ph = xform44(px, py, pz, proj);
+            const float pw = 1.0f / (ph.w + 0.0000001f);
+            const float projx = ph.x * pw, projy = ph.y * pw;
+            float c6[6];
+            if (cov_pre) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) c6[k] = cov_pre[6 * (size_t)idx + k];
+            } else {
+                const float4 q = ((const float4*)rots)[idx];
+                cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], mod, q.x, q.y, q.z,
+                                     q.w, c6);
+            }
+            const Cov2D k = cov2d_eval(px, py, pz, cam, view, c6);
+            const float det = k.a * k.c - k.b * k.b;
+            if (det != 0.0f) {
+                const float dinv = 1.f / det;
+                const float mid = 0.5f * (k.a + k.c);
+                const float l1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float l2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float rad = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+                const float ix = ndc_to_pix(projx, cam.W), iy = ndc_to_pix(projy, cam.H);
+                const int ri = (int)rad;  // v_cvt_i32_f32 saturates like the reference's conversion
+                int a;
+                a = max(0, (int)((ix - ri) / NGS_TILE_W)); const uint32_t x0 = min((uint32_t)cam.grid_x, (uint32_t)a);
+                a = max(0, (int)((iy - ri) / NGS_TILE_H)); const uint32_t y0 = min((uint32_t)cam.grid_y, (uint32_t)a);
+                a = max(0, (int)((ix + ri + NGS_TILE_W - 1) / NGS_TILE_W)); const uint32_t x1 = min((uint32_t)cam.grid_x, (uint32_t)a);
+                a = max(0, (int)((iy + ri + NGS_TILE_H - 1) / NGS_TILE_H)); const uint32_t y1 = min((uint32_t)cam.grid_y, (uint32_t)a);
+                const uint32_t area = (x1 - x0) * (y1 - y0);
+                if (area != 0) {
+                    float3 col;
+                    uint32_t cb = 0;
+                    if (col_pre) {
+                        col = make_float3(col_pre[3 * (size_t)idx], col_pre[3 * (size_t)idx + 1],
+                                          col_pre[3 * (size_t)idx + 2]);
+                    } else {
+                        float3 d = make_float3(px - campos[0], py - campos[1], pz - campos[2]);
+                        const float len = sqrtf(f3_dot(d, d));
+                        d = make_float3(d.x / len, d.y / len, d.z / len);
+                        col = sh_to_rgb(D, shs + (size_t)3 * M * idx, d, cb);
+                    }
+                    g0[idx] = make_float4(ix, iy, k.c * dinv, -k.b * dinv);
+                    g1[idx] = make_float4(k.a * dinv, opac[idx], col.x, col.y);
+                    g2[idx] = col.z;
+                    depth[idx] = pv.z;
+                    rect[idx] = make_uint2(x0 | (x1 << 16), y0 | (y1 << 16));
+                    clamped[idx] = (uint8_t)cb;
+                    my_radius = ri;
+                    my_tiles = area;
+                }
+            }
+        }
+        radii[idx] = my_radius;
+        tiles[idx] = my_tiles;
+    }
+    // Tiles touched by this block of 256 Gaussians: the first level of the instance-offset scan.
+    const uint32_t ws = wave_sum_u32(my_tiles);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// rasterizer_impl.cu:54-66: present[i] = view-space z > 0.2
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means,
+                                                            const float* __restrict__ view,
+                                                            uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float3 pv = xform43(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2], view);
+    present[idx] = pv.z > 0.2f ? 1 : 0;
+}
+
+void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* means, const float* scales, float mod,
+                               const float* rots, const float* opac, const float* shs, const float* cov_pre,
+                               const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* g0,
+                               float4* g1, float* g2, float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
+                               uint32_t* block_sums, uint32_t* misc)
+{
+    const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales, mod, rots,
+                       opac, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered, radii, g0, g1, g2, depth, rect, tiles, clamped,
+                       block_sums, misc);
+}
+
+void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const float* view, uint8_t* present)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means, view, present);
+}

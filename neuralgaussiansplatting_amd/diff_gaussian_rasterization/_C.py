@@ -1,0 +1,181 @@
+"""Binding layer between torch tensors and ``libngs_rasterizer.so``.
+
+Plays the role of the reference's compiled ``_C`` module (pybind names at
+submodules/diff-gaussian-rasterization/ext.cpp:15-19, marshalling at
+rasterize_points.cu:35-217): the three functions below keep its names,
+argument order and return tuples.  The product path is the HIP library; there
+is no CPU fallback, and a missing library or a non-GPU tensor is an error.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libngs_rasterizer.so")
+NUM_CHANNELS = 3  # cuda_rasterizer/config.h:15
+
+_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libngs_rasterizer.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C neuralgaussiansplatting_amd/csrc`" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.ngs_last_error.restype = ctypes.c_char_p
+        for name in ("ngs_required_geometry_bytes", "ngs_required_binning_bytes", "ngs_required_image_bytes"):
+            getattr(L, name).restype = ctypes.c_size_t
+        L.ngs_required_binning_bytes.argtypes = [ctypes.c_longlong]
+        L.ngs_rasterize_forward.restype = ctypes.c_int
+        L.ngs_rasterize_backward.restype = ctypes.c_int
+        L.ngs_mark_visible.restype = ctypes.c_int
+        L.ngs_state_layout.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().ngs_last_error().decode())
+
+
+def _ptr(t):
+    """Device address of a contiguous float/int tensor; NULL for an empty one,
+    which is how the reference signals an absent optional input."""
+    if t is None or t.numel() == 0:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t, device):
+    if t.numel() == 0:
+        return t
+    if t.device != device:
+        raise RuntimeError("all rasterizer inputs must live on %s (got %s)" % (device, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("rasterizer inputs must be float32 (got %s)" % t.dtype)
+    return t.contiguous()
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("the rasterizer runs on the GPU only: means3D is on %s" % t.device)
+
+
+class _Growable:
+    """A byte tensor the library grows through its allocator callback
+    (the reference's resizeFunctional, rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _ALLOC_FN(self._grow)
+
+    def _grow(self, _ctx, nbytes):
+        self.t.resize_(int(nbytes))
+        return self.t.data_ptr()
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """-> (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)"""
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_gpu(means3D)
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    means3D, colors, opacity, scales, rotations, cov3D_precomp, sh = (
+        _f32(x, dev) for x in (means3D, colors, opacity, scales, rotations, cov3D_precomp, sh))
+    background, viewmatrix, projmatrix, campos = (_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
+    geom, binning, img = _Growable(dev), _Growable(dev), _Growable(dev)
+    rendered = ctypes.c_int(0)
+    if P != 0:
+        out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        M = sh.size(1) if sh.numel() != 0 else 0
+        with torch.cuda.device(dev):
+            _check(lib().ngs_rasterize_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), _ptr(background), W, H,
+                _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), ctypes.c_float(scale_modifier),
+                _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
+                ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy), int(bool(prefiltered)), _ptr(out_color),
+                _ptr(radii), int(bool(debug)), _stream(dev), ctypes.byref(rendered)))
+    else:
+        out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    return rendered.value, out_color, radii, geom.t, binning.t, img.t
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
+                                 return_conic=False):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    (rasterize_points.cu:195); with ``return_conic`` a ninth element dL_dconic [P,2,2] is appended."""
+    _require_gpu(means3D)
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    means3D, colors, scales, rotations, cov3D_precomp, sh, dL_dout_color = (
+        _f32(x, dev) for x in (means3D, colors, scales, rotations, cov3D_precomp, sh, dL_dout_color))
+    background, viewmatrix, projmatrix, campos = (_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
+    # The library writes every element of every output, so no zero fill is needed when P > 0.
+    mk = torch.empty if P != 0 else torch.zeros
+    opts = dict(dtype=torch.float32, device=dev)
+    dL_dmeans3D = mk((P, 3), **opts)
+    dL_dmeans2D = mk((P, 3), **opts)
+    dL_dcolors = mk((P, NUM_CHANNELS), **opts)
+    dL_dconic = mk((P, 2, 2), **opts) if return_conic else None
+    dL_dopacity = mk((P, 1), **opts)
+    dL_dcov3D = mk((P, 6), **opts)
+    dL_dsh = mk((P, M, 3), **opts)
+    dL_dscales = mk((P, 3), **opts)
+    dL_drotations = mk((P, 4), **opts)
+    if P != 0:
+        with torch.cuda.device(dev):
+            _check(lib().ngs_rasterize_backward(
+                P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                _ptr(scales), ctypes.c_float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                _ptr(projmatrix), _ptr(campos), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy),
+                _ptr(radii.contiguous()), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
+                int(bool(debug)), _stream(dev)))
+    out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    return out + (dL_dconic,) if return_conic else out
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """-> bool[P] (rasterize_points.cu:198-217)"""
+    _require_gpu(means3D)
+    dev = means3D.device
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        means3D, viewmatrix, projmatrix = (_f32(x, dev) for x in (means3D, viewmatrix, projmatrix))
+        with torch.cuda.device(dev):
+            _check(lib().ngs_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), _ptr(present),
+                                          _stream(dev)))
+    return present
+
+
+def state_layout(P, R, W, H):
+    """Byte offsets of the intermediates inside the three state buffers (parity tests)."""
+    g = (ctypes.c_size_t * 12)()
+    b = (ctypes.c_size_t * 2)()
+    i = (ctypes.c_size_t * 3)()
+    lib().ngs_state_layout(int(P), ctypes.c_longlong(int(R)), int(W), int(H), g, b, i)
+    names_g = ("xy_conicab", "conicc_opacity_rg", "blue", "depth", "tile_rect", "tiles_touched", "internal_radii",
+               "clamped_bits", "block_sums", "block_offsets", "misc", "grad_accumulator")
+    return (dict(zip(names_g, g)), dict(zip(("sorted_keys", "point_list"), b)),
+            dict(zip(("final_T", "n_contrib", "ranges"), i)))

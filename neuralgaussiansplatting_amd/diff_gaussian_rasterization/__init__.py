@@ -1,0 +1,114 @@
+"""Drop-in ``diff_gaussian_rasterization`` package backed by the gfx950 HIP library.
+
+Public names, argument orders, return orders and error behaviour are those of
+the reference package
+(submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py):
+``GaussianRasterizationSettings`` (:157-169), ``GaussianRasterizer`` (:171-220),
+``rasterize_gaussians`` (:21-42) and ``_RasterizeGaussians`` (:44-155), so
+``gaussian_renderer.render()`` (gaussian_renderer/__init__.py:14,52,86) runs
+against it unchanged.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call_with_snapshot(fn, args, debug, dump_name, what):
+    """In debug mode keep a CPU copy of the arguments and dump it if the native
+    call raises (reference :83-90 and :132-139)."""
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_name)
+        print("\nAn error occured in %s. Please forward %s for debugging." % (what, dump_name))
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        num_rendered, color, radii, geom, binning, img = _call_with_snapshot(
+            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
+                              img)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
+                geom, ctx.num_rendered, binning, img, rs.debug)
+        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _call_with_snapshot(
+            _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        # one gradient per forward input, in input order; none for the settings
+        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of the points that pass the near-plane test for this camera."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_pair = scales is not None and rotations is not None
+        has_any = scales is not None or rotations is not None
+        if (not has_pair and cov3D_precomp is None) or (has_any and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        # absent optionals travel as empty tensors (NULL data pointer in the native call)
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)

@@ -1,0 +1,165 @@
+"""numpy front-end of the CPU checker in ``ngs_oracle.c``.
+
+TEST INFRASTRUCTURE ONLY.  Importable from ``tests/``, ``__graft_entry__.smoke``
+and the ``cpu_baseline`` leg of ``bench.py``; the shipped package never imports
+it.  ``forward`` / ``backward`` run the stages in the order of the reference's
+``Rasterizer::forward`` / ``::backward``
+(submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer_impl.cu:198-434)
+and hand back every intermediate so that the HIP path can be compared stage by
+stage.  Parity status of each stage: see the header of ``ngs_oracle.c``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libngs_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ngs_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libngs_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.ngs_oracle_higher_msb.restype = ctypes.c_uint32
+        _lib.ngs_oracle_threads.restype = ctypes.c_int
+        _lib.ngs_oracle_preprocess.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return ctypes.c_void_p(0)
+    assert a.flags["C_CONTIGUOUS"]
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def set_threads(n):
+    lib().ngs_oracle_set_threads(int(n))
+
+
+def threads():
+    return int(lib().ngs_oracle_threads())
+
+
+def higher_msb(n):
+    return int(lib().ngs_oracle_higher_msb(ctypes.c_uint32(n)))
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    means3D = _f32(means3D)
+    P = means3D.shape[0]
+    out = np.zeros(P, dtype=np.uint8)
+    lib().ngs_oracle_mark_visible(P, _p(means3D), _p(_f32(viewmatrix)), _p(_f32(projmatrix)), _p(out))
+    return out.astype(bool)
+
+
+def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, sh_degree=0, shs=None,
+            colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0,
+            prefiltered=False):
+    """Returns a dict with every intermediate of the reference's forward pass."""
+    L = lib()
+    means3D = _f32(means3D)
+    P = means3D.shape[0]
+    shs, colors_precomp, scales, rotations, cov3D_precomp = map(_f32, (shs, colors_precomp, scales, rotations,
+                                                                       cov3D_precomp))
+    opacities, viewmatrix, projmatrix, campos, bg = map(_f32, (opacities, viewmatrix, projmatrix, campos, bg))
+    M = 0 if shs is None or shs.size == 0 else shs.shape[1]
+    if shs is not None and shs.size == 0:
+        shs = None
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    s = dict(P=P, W=W, H=H, M=M, D=sh_degree, grid=(gx, gy))
+    s["radii"] = np.zeros(P, np.int32)
+    s["means2D"] = np.zeros((P, 2), np.float32)
+    s["depths"] = np.zeros(P, np.float32)
+    s["cov3D"] = np.zeros((P, 6), np.float32)
+    s["rgb"] = np.zeros((P, 3), np.float32)
+    s["conic_opacity"] = np.zeros((P, 4), np.float32)
+    s["tiles_touched"] = np.zeros(P, np.uint32)
+    s["clamped"] = np.zeros((P, 3), np.uint8)
+    s["out_color"] = np.zeros((3, H, W), np.float32)
+    s["final_T"] = np.zeros((H, W), np.float32)
+    s["n_contrib"] = np.zeros((H, W), np.uint32)
+    s["ranges"] = np.zeros((gx * gy, 2), np.uint32)
+    s["num_rendered"] = 0
+    if P == 0:
+        return s
+    bad = L.ngs_oracle_preprocess(
+        P, int(sh_degree), M, _p(means3D), _p(scales), ctypes.c_float(scale_modifier), _p(rotations), _p(opacities),
+        _p(shs), _p(cov3D_precomp), _p(colors_precomp), _p(viewmatrix), _p(projmatrix), _p(campos), W, H,
+        ctypes.c_float(tanfovx), ctypes.c_float(tanfovy), int(bool(prefiltered)), _p(s["radii"]), _p(s["means2D"]),
+        _p(s["depths"]), _p(s["cov3D"]), _p(s["rgb"]), _p(s["conic_opacity"]), _p(s["tiles_touched"]),
+        _p(s["clamped"]))
+    if bad:
+        raise RuntimeError("Point is filtered although prefiltered is set.")
+    s["point_offsets"] = np.zeros(P, np.uint32)
+    L.ngs_oracle_scan(P, _p(s["tiles_touched"]), _p(s["point_offsets"]))
+    R = int(s["point_offsets"][-1])
+    s["num_rendered"] = R
+    s["keys_unsorted"] = np.zeros(R, np.uint64)
+    s["values_unsorted"] = np.zeros(R, np.uint32)
+    L.ngs_oracle_duplicate(P, _p(s["means2D"]), _p(s["depths"]), _p(s["point_offsets"]), _p(s["radii"]), W, H,
+                           _p(s["keys_unsorted"]), _p(s["values_unsorted"]))
+    s["sort_bits"] = 32 + higher_msb(gx * gy)
+    s["keys_sorted"] = np.zeros(R, np.uint64)
+    s["point_list"] = np.zeros(R, np.uint32)
+    L.ngs_oracle_sort_pairs(ctypes.c_int64(R), _p(s["keys_unsorted"]), _p(s["values_unsorted"]), _p(s["keys_sorted"]),
+                            _p(s["point_list"]), s["sort_bits"])
+    L.ngs_oracle_tile_ranges(ctypes.c_int64(R), _p(s["keys_sorted"]), gx * gy, _p(s["ranges"]))
+    s["features"] = colors_precomp if colors_precomp is not None and colors_precomp.size else s["rgb"]
+    L.ngs_oracle_render_forward(W, H, _p(s["ranges"]), _p(s["point_list"]), _p(s["means2D"]), _p(s["features"]),
+                                _p(s["conic_opacity"]), _p(bg), _p(s["final_T"]), _p(s["n_contrib"]),
+                                _p(s["out_color"]))
+    return s
+
+
+def backward(s, dL_dpix, means3D, viewmatrix, projmatrix, campos, bg, tanfovx, tanfovy, shs=None,
+             colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0):
+    """Gradients in the layout of ``RasterizeGaussiansBackwardCUDA``
+    (submodules/diff-gaussian-rasterization/rasterize_points.cu:151-159)."""
+    L = lib()
+    P, W, H, M, D = s["P"], s["W"], s["H"], s["M"], s["D"]
+    means3D = _f32(means3D)
+    shs, colors_precomp, scales, rotations, cov3D_precomp = map(_f32, (shs, colors_precomp, scales, rotations,
+                                                                       cov3D_precomp))
+    if shs is not None and shs.size == 0:
+        shs = None
+    viewmatrix, projmatrix, campos, bg, dL_dpix = map(_f32, (viewmatrix, projmatrix, campos, bg, dL_dpix))
+    g = dict(
+        dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dmeans2D=np.zeros((P, 3), np.float32),
+        dL_dcolors=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 2, 2), np.float32),
+        dL_dopacity=np.zeros((P, 1), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
+        dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 3), np.float32),
+        dL_drotations=np.zeros((P, 4), np.float32))
+    if P == 0:
+        return g
+    L.ngs_oracle_render_backward(W, H, _p(s["ranges"]), _p(s["point_list"]), _p(bg), _p(s["means2D"]),
+                                 _p(s["conic_opacity"]), _p(s["features"]), _p(s["final_T"]), _p(s["n_contrib"]),
+                                 _p(dL_dpix), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]),
+                                 _p(g["dL_dcolors"]))
+    fy = np.float32(H) / (np.float32(2.0) * np.float32(tanfovy))
+    fx = np.float32(W) / (np.float32(2.0) * np.float32(tanfovx))
+    cov3d = cov3D_precomp if cov3D_precomp is not None and cov3D_precomp.size else s["cov3D"]
+    L.ngs_oracle_cov2d_backward(P, _p(means3D), _p(s["radii"]), _p(cov3d), ctypes.c_float(fx), ctypes.c_float(fy),
+                                ctypes.c_float(tanfovx), ctypes.c_float(tanfovy), _p(viewmatrix), _p(g["dL_dconic"]),
+                                _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]))
+    L.ngs_oracle_preprocess_backward(P, D, M, _p(means3D), _p(s["radii"]), _p(shs), _p(s["clamped"]), _p(scales),
+                                     _p(rotations), ctypes.c_float(scale_modifier), _p(projmatrix), _p(campos),
+                                     _p(g["dL_dmeans2D"]), _p(g["dL_dmeans3D"]), _p(g["dL_dcolors"]),
+                                     _p(g["dL_dcov3D"]), _p(g["dL_dsh"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
+    return g

@@ -1,0 +1,224 @@
+"""GPU parity: the HIP library, called through its C ABI via the drop-in
+package, against the CPU checker on the same seeded inputs.
+
+Bar: integers derived on the per-Gaussian/binning path (radii, tiles touched,
+tile rectangles, sorted keys, point list, tile ranges, instance count) are
+bit-exact; rendered RGB is within 1e-5 abs; gradients of a loss with
+dL/dpixel ~ N(0,1)/(W*H) are within 1e-5 abs, and additionally within 2e-4 of
+each tensor's largest magnitude for an un-normalised dL/dpixel ~ N(0,1).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import case, decode_state, oracle_backward, oracle_forward
+
+pytestmark = pytest.mark.gpu
+
+RGB_ATOL = 1e-5
+GRAD_ATOL = 1e-5
+GRAD_REL_TO_MAX = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dgr():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from neuralgaussiansplatting_amd import diff_gaussian_rasterization as m
+    m._C.lib()  # fail loudly if the HIP library is missing
+    return m
+
+
+def run_hip(dgr, c, dL_dpix=None, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0, prefiltered=False,
+            debug=False):
+    dev = torch.device("cuda:0")
+    sc, cam = c["scene"], c["cam"]
+    e = torch.empty(0)
+    g = lambda t: t.to(dev)
+    args = (g(c["bg"]), g(sc.means3D), e if colors_precomp is None else g(colors_precomp), g(sc.opacities),
+            g(sc.scales) if cov3D_precomp is None else e, g(sc.rotations) if cov3D_precomp is None else e,
+            scale_modifier, e if cov3D_precomp is None else g(cov3D_precomp), g(cam.world_view_transform),
+            g(cam.full_proj_transform), c["tanfovx"], c["tanfovy"], c["H"], c["W"],
+            g(sc.shs) if colors_precomp is None else e, c["D"], g(cam.camera_center), prefiltered, debug)
+    R, color, radii, geom, binning, img = dgr._C.rasterize_gaussians(*args)
+    torch.cuda.synchronize()
+    out = dict(R=R, color=color.cpu().numpy(), radii=radii.cpu().numpy())
+    P = sc.means3D.shape[0]
+    if P:
+        out.update(decode_state(dgr._C, P, R, c["W"], c["H"], geom, binning, img))
+    if dL_dpix is not None:
+        bargs = (args[0], args[1], radii, args[2], args[4], args[5], scale_modifier, args[7], args[8], args[9],
+                 c["tanfovx"], c["tanfovy"], g(dL_dpix), args[14], c["D"], args[16], geom, R, binning, img, debug)
+        names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+                 "dL_drotations", "dL_dconic")
+        res = dgr._C.rasterize_gaussians_backward(*bargs, return_conic=True)
+        torch.cuda.synchronize()
+        out["grads"] = {n: t.cpu().numpy() for n, t in zip(names, res)}
+    return out
+
+
+def check_forward(o, h, exact_pixels=True):
+    assert h["R"] == o["num_rendered"]
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    vis = o["radii"] > 0
+    np.testing.assert_array_equal(h["tiles_touched"], o["tiles_touched"])
+    np.testing.assert_array_equal(h["depths"][vis].view(np.uint32), o["depths"][vis].view(np.uint32))
+    np.testing.assert_array_equal(h["means2D"][vis].view(np.uint32), o["means2D"][vis].view(np.uint32))
+    np.testing.assert_allclose(h["conic_opacity"][vis], o["conic_opacity"][vis], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(h["rgb"][vis], o["features"][vis], rtol=0, atol=1e-6)
+    if "clamped" in o and o["M"]:
+        bits = o["clamped"][:, 0] | (o["clamped"][:, 1] << 1) | (o["clamped"][:, 2] << 2)
+        np.testing.assert_array_equal(h["clamped_bits"][vis], bits[vis])
+    np.testing.assert_array_equal(h["keys_sorted"], o["keys_sorted"])
+    np.testing.assert_array_equal(h["point_list"], o["point_list"])
+    np.testing.assert_array_equal(h["ranges"], o["ranges"])
+    np.testing.assert_allclose(h["color"], o["out_color"], rtol=0, atol=RGB_ATOL)
+    np.testing.assert_allclose(h["final_T"], o["final_T"], rtol=0, atol=RGB_ATOL)
+    if exact_pixels:
+        np.testing.assert_array_equal(h["n_contrib"], o["n_contrib"])
+    else:  # exp() differs by an ulp between libm and the GPU: allow a knife-edge pixel or two
+        assert (h["n_contrib"] != o["n_contrib"]).mean() < 1e-4
+
+
+def check_grads(hg, og, scale=1.0):
+    for name, ref in og.items():
+        got = hg[name].reshape(ref.shape)
+        big = float(np.abs(ref).max()) if ref.size else 0.0
+        err = float(np.abs(got - ref).max()) if ref.size else 0.0
+        assert err <= GRAD_REL_TO_MAX * big + 1e-7 * scale, "%s: max err %g vs max magnitude %g" % (name, err, big)
+        # the stated bar, for the loss normalised by the pixel count
+        assert err / scale <= GRAD_ATOL, "%s: abs err %g" % (name, err / scale)
+
+
+CASES = {
+    "c1_sh0_64x64": dict(P=256, W=64, H=64, D=0),
+    "sh3_64x64": dict(P=300, W=64, H=64, D=3, M=16, seed=7),
+    "sh1_of_16_coeffs": dict(P=200, W=48, H=48, D=1, M=16, seed=11),
+    "sh2_ragged_40x24": dict(P=180, W=40, H=24, D=2, M=9, seed=3),
+    "camera_inside_cloud": dict(P=400, W=64, H=48, D=3, M=16, seed=5, eye=(0.1, 0.05, -0.4)),
+    "big_splats": dict(P=64, W=96, H=80, D=0, log_scale=(-1.5, -0.5), seed=9),
+    "white_bg": dict(P=256, W=64, H=64, D=0, bg=(1.0, 1.0, 1.0), seed=13),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_forward_backward_matches_oracle(name, dgr, oracle):
+    c = case(**CASES[name])
+    g = torch.Generator().manual_seed(99)
+    dL = torch.randn(3, c["H"], c["W"], generator=g)
+    o = oracle_forward(oracle, c)
+    h = run_hip(dgr, c, dL_dpix=dL)
+    check_forward(o, h)
+    og = oracle_backward(oracle, c, o, dL)
+    check_grads(h["grads"], og, scale=float(c["W"] * c["H"]))
+
+
+def test_culled_and_offscreen_gaussians(dgr, oracle):
+    c = case(P=500, W=64, H=64, D=0, seed=21, eye=(0.0, 0.0, -0.6), extent=(1.5, 1.5, 1.3))
+    o = oracle_forward(oracle, c)
+    assert (o["radii"] == 0).sum() > 50 and (o["radii"] > 0).sum() > 50  # both kinds present
+    dL = torch.randn(3, 64, 64, generator=torch.Generator().manual_seed(1))
+    h = run_hip(dgr, c, dL_dpix=dL)
+    check_forward(o, h)
+    og = oracle_backward(oracle, c, o, dL)
+    check_grads(h["grads"], og, scale=64.0 * 64.0)
+    for n in ("dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dopacity"):
+        assert not h["grads"][n][o["radii"] == 0].any(), n  # culled Gaussians get exact zeros
+
+
+def test_precomputed_colors_and_covariance(dgr, oracle):
+    from neuralgaussiansplatting_amd.gaussian_model import covariance_from_scaling_rotation
+    c = case(P=256, W=64, H=64, D=0, seed=17)
+    sc = c["scene"]
+    cols = torch.rand(256, 3, generator=torch.Generator().manual_seed(2))
+    cov = covariance_from_scaling_rotation(sc.scales, 1.0, sc.rotations).contiguous()
+    dL = torch.randn(3, 64, 64, generator=torch.Generator().manual_seed(3))
+    o = oracle_forward(oracle, c, colors_precomp=cols, cov3D_precomp=cov)
+    h = run_hip(dgr, c, dL_dpix=dL, colors_precomp=cols, cov3D_precomp=cov)
+    check_forward(o, h)
+    og = oracle_backward(oracle, c, o, dL, colors_precomp=cols, cov3D_precomp=cov)
+    check_grads(h["grads"], og, scale=64.0 * 64.0)
+    assert not h["grads"]["dL_dscales"].any() and not h["grads"]["dL_drotations"].any()
+    # known-answer cross-check (the reference's compute_cov3D_python switch): the precomputed-covariance path
+    # renders the same image as the scale/rotation path
+    h2 = run_hip(dgr, c, colors_precomp=cols)
+    np.testing.assert_allclose(h["color"], h2["color"], atol=2e-4)
+
+
+def test_scale_modifier(dgr, oracle):
+    c = case(P=256, W=64, H=64, D=0, seed=19)
+    dL = torch.randn(3, 64, 64, generator=torch.Generator().manual_seed(4))
+    o = oracle_forward(oracle, c, scale_modifier=0.6)
+    h = run_hip(dgr, c, dL_dpix=dL, scale_modifier=0.6)
+    check_forward(o, h)
+    check_grads(h["grads"], oracle_backward(oracle, c, o, dL, scale_modifier=0.6), scale=64.0 * 64.0)
+
+
+def test_debug_mode_same_result(dgr, oracle):
+    c = case(P=128, W=32, H=32, D=0, seed=23)
+    o = oracle_forward(oracle, c)
+    check_forward(o, run_hip(dgr, c, debug=True))
+
+
+def test_config2_100k_800x800(dgr, oracle):
+    """BASELINE configuration 2 at full size, per-pixel match."""
+    oracle.set_threads(8)
+    try:
+        from neuralgaussiansplatting_amd import synthetic
+        sc, W, H = synthetic.make_config("c2")
+        cam = synthetic.make_view(W, H, 0)
+        c = dict(scene=sc, cam=cam, W=W, H=H, D=0, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
+                 tanfovy=math.tan(cam.FoVy * 0.5))
+        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(5))
+        o = oracle_forward(oracle, c)
+        assert 2.0 < o["num_rendered"] / 100_000 < 8.0
+        h = run_hip(dgr, c, dL_dpix=dL)
+        check_forward(o, h, exact_pixels=False)
+        oracle.set_threads(1)
+        og = oracle_backward(oracle, c, o, dL)
+        check_grads(h["grads"], og, scale=float(W * H))
+    finally:
+        oracle.set_threads(1)
+
+
+def test_empty_scene(dgr):
+    dev = torch.device("cuda:0")
+    e = torch.empty(0)
+    z = torch.zeros(0, 3, device=dev)
+    cam = case(P=1, W=32, H=16, D=0)["cam"]
+    R, color, radii, g, b, i = dgr._C.rasterize_gaussians(
+        torch.zeros(3, device=dev), z, e, torch.zeros(0, 1, device=dev), z, torch.zeros(0, 4, device=dev), 1.0, e,
+        cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 0.3, 0.2, 16, 32,
+        torch.zeros(0, 1, 3, device=dev), 0, cam.camera_center.to(dev), False, False)
+    assert R == 0 and color.shape == (3, 16, 32) and not color.any() and radii.numel() == 0
+    assert g.numel() == 0 and b.numel() == 0 and i.numel() == 0
+
+
+def test_bad_means_shape_raises(dgr):
+    dev = torch.device("cuda:0")
+    e = torch.empty(0)
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        dgr._C.rasterize_gaussians(torch.zeros(3, device=dev), torch.zeros(4, 2, device=dev), e, e, e, e, 1.0, e,
+                                   torch.eye(4, device=dev), torch.eye(4, device=dev), 0.3, 0.3, 16, 16, e, 0,
+                                   torch.zeros(3, device=dev), False, False)
+
+
+def test_prefiltered_with_culled_point_is_an_error(dgr):
+    c = case(P=500, W=64, H=64, D=0, seed=21, eye=(0.0, 0.0, -0.6), extent=(1.5, 1.5, 1.3))
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        run_hip(dgr, c, prefiltered=True)
+
+
+def test_mark_visible(dgr, oracle):
+    c = case(P=1000, W=64, H=64, D=0, seed=29, eye=(0.0, 0.0, -0.5))
+    dev = torch.device("cuda:0")
+    cam = c["cam"]
+    settings = dgr.GaussianRasterizationSettings(64, 64, c["tanfovx"], c["tanfovy"], c["bg"].to(dev), 1.0,
+                                                 cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 0,
+                                                 cam.camera_center.to(dev), False, False)
+    vis = dgr.GaussianRasterizer(settings).markVisible(c["scene"].means3D.to(dev)).cpu().numpy()
+    ref = oracle.mark_visible(c["scene"].means3D.numpy(), cam.world_view_transform.numpy(),
+                              cam.full_proj_transform.numpy())
+    assert vis.dtype == np.bool_ and 0 < vis.sum() < 1000
+    np.testing.assert_array_equal(vis, ref)
