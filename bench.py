@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the rasterizer hot path: forward + backward of one camera view
+per GPU on a synthetic scene, through the C ABI of libngs_rasterizer.so.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A step = preprocess -> scan -> key emission -> radix sort -> tile ranges ->
+compositing forward, then compositing backward -> per-Gaussian backward, on
+inputs already resident in HBM; with N > 1 each rank renders its own view of
+the replicated scene and the step ends with one all-reduce (RCCL) of the
+per-Gaussian gradient bucket.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from neuralgaussiansplatting_amd import synthetic, view_parallel  # noqa: E402
+from neuralgaussiansplatting_amd.debug_state import decode_state  # noqa: E402
+from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def stage_bytes(P, R, W, H, D, M, vis):
+    """Algorithmic HBM bytes of one launch of each stage (per-unit figures in DESIGN.md)."""
+    c = (D + 1) ** 2
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    passes = (32 + T.bit_length() + 7) // 8  # bit_length(T) is the reference's getHigherMsb(T)
+    vP = vis * P
+    return {
+        "preprocess_fwd": P * (12 + 8) + vP * (32 + 12 * c + 49),
+        "scan_block_sums": 8 * ((P + 255) // 256),
+        "duplicate_with_keys": 4 * P + 12 * vP + 12 * R,
+        "radix_sort": passes * 24 * R,
+        "tile_ranges": 8 * R + 16 * T,
+        "render_fwd": 40 * R + 8 * T + 20 * W * H,
+        "zero_accumulator": 64 * P,
+        "render_bwd": 112 * R + 8 * T + 20 * W * H,
+        "preprocess_bwd": 4 * P + vP * (105 + 12 * c) + P * (92 + 12 * M),
+    }
+
+
+def cpu_baseline(scene, cam, W, H, D, tanx, tany, dL):
+    """The CPU checker (a port of the reference's algorithm) timed on this box's cores: one forward+backward
+    of the same workload."""
+    from oracle import oracle as orc
+    orc.build()
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    orc.set_threads(cores)
+    a = lambda t: t.detach().cpu().numpy()
+    t0 = time.time()
+    st = orc.forward(a(scene.means3D), a(scene.opacities), a(cam.world_view_transform), a(cam.full_proj_transform),
+                     a(cam.camera_center), np.zeros(3, np.float32), W, H, tanx, tany, sh_degree=D, shs=a(scene.shs),
+                     scales=a(scene.scales), rotations=a(scene.rotations))
+    t1 = time.time()
+    orc.backward(st, a(dL), a(scene.means3D), a(cam.world_view_transform), a(cam.full_proj_transform),
+                 a(cam.camera_center), np.zeros(3, np.float32), tanx, tany, shs=a(scene.shs), scales=a(scene.scales),
+                 rotations=a(scene.rotations))
+    t2 = time.time()
+    return {"value": W * H / (t2 - t0) / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "1 forward+backward of the same view and scene (fwd %.2f s, bwd %.2f s, R=%d)"
+                      % (t1 - t0, t2 - t1, st["num_rendered"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c4", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the rasterizer has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    P, W, H, D, M, _, _ = synthetic.CONFIGS[args.config]
+    scene_cpu, W, H = synthetic.make_config(args.config, seed=1234)  # same seed everywhere: replicated parameters
+    scene = scene_cpu.to(dev)
+    cam = synthetic.make_view(W, H, index=rank, count=8, device=dev)  # one orbit view per rank
+    tanx, tany = synthetic.tan_half_fov(cam)
+    bg = torch.zeros(3, device=dev)
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    dL = (torch.randn(3, H, W, generator=gen) / float(W * H)).to(dev)
+    bucket = view_parallel.GradientBucket(P, M, dev)
+
+    def step():
+        out = view_parallel.forward_backward(scene, cam, bg, lambda color: dL, bucket, tanx, tany)
+        bucket.all_reduce()
+        return out
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        color, radii, aux = step()
+    # workload statistics of this rank's view (cost is linear in them)
+    R = aux["num_rendered"]
+    vis = float((radii > 0).float().mean())
+    _C.profile_enable(not args.no_stage_timing)
+    _C.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stages = _C.profile_read(reset=True)
+    _C.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * W * H * args.steps / elapsed / 1e6
+        # statistics that need the state buffers: one extra untimed forward
+        e = torch.empty(0)
+        Rr, _, radii2, geom, binning, img = _C.rasterize_gaussians(
+            bg, scene.means3D, e, scene.opacities, scene.scales, scene.rotations, 1.0, e, cam.world_view_transform,
+            cam.full_proj_transform, tanx, tany, H, W, scene.shs, D, cam.camera_center, False, False)
+        stt = decode_state(_C, P, Rr, W, H, geom, binning, img)
+        per_tile = (stt["ranges"][:, 1] - stt["ranges"][:, 0]).astype(np.int64)
+        nbytes = stage_bytes(P, R, W, H, D, M, vis)
+        stage_out, dom, dom_ms = {}, None, 0.0
+        for name, (tot, cnt) in stages.items():
+            if cnt == 0:
+                continue
+            avg = tot / cnt
+            gbs = nbytes[name] / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+            stage_out[name] = {"ms": round(avg, 4), "launches": cnt, "algorithmic_GB": round(nbytes[name] / 1e9, 4),
+                               "GB_per_s": round(gbs, 1)}
+            if avg > dom_ms:
+                dom, dom_ms = name, avg
+        roofline = None
+        if dom is not None:
+            ach = nbytes[dom] / (dom_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get(args.config, {}).get(dom)
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes": int(nbytes[dom])}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(scene_cpu, synthetic.make_view(W, H, index=0, count=8), W, H, D, tanx, tany, dL)
+        line = {
+            "metric": "fwd+bwd Mpixels/s (rasterizer forward+backward, 1080p / 3M Gaussians per GPU)"
+                      if args.config == "c4" else "fwd+bwd Mpixels/s (rasterizer forward+backward)",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "iters_per_s": round(world * args.steps / elapsed, 2),
+            "config": {"workload": "%s: %d Gaussians, %dx%d, SH degree %d (M=%d), one orbit view per GPU, "
+                                   "fwd+bwd%s" % (args.config, P, W, H, D, M,
+                                                  " + all-reduce of %d floats" % bucket.flat.numel() if world > 1
+                                                  else ""),
+                       "gaussians": P, "width": W, "height": H, "sh_degree": D, "instances_R": int(R),
+                       "visible_fraction": round(vis, 4), "instances_per_tile_mean": round(float(per_tile.mean()), 1),
+                       "instances_per_tile_max": int(per_tile.max()),
+                       "last_contributor_per_pixel_mean": round(float(stt["n_contrib"].mean()), 1),
+                       "parallelism": "view-sharded dp%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "stages": stage_out,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

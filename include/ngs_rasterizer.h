@@ -59,9 +59,8 @@ int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_a
 /*
  * Rasterizer::backward (rasterizer.h:55-84, rasterizer_impl.cu:340-434).
  * geom_buffer / binning_buffer / image_buffer are the buffers the forward call
- * filled (same base addresses or copies of their contents at any 1-byte
- * alignment the allocator produced; they are re-carved from P, R and the image
- * size).  Every output element is WRITTEN (zeros for culled Gaussians), so
+ * filled (or copies of them at addresses with the same residue modulo 256;
+ * they are re-carved from P, R and the image size).  Every output element is WRITTEN (zeros for culled Gaussians), so
  * the caller need not zero-fill; dL_dconic ([P][2][2]) may be NULL.
  * Shapes: dL_dpix [3][H][W]; dL_dmean2D [P][3]; dL_dopacity [P]; dL_dcolor
  * [P][3]; dL_dmean3D [P][3]; dL_dcov3D [P][6]; dL_dsh [P][M][3]; dL_dscale
@@ -99,6 +98,20 @@ size_t ngs_required_image_bytes(int width, int height);
  * No counterpart in the reference (its state structs are private, rasterizer_impl.h:29-65).
  */
 int ngs_state_layout(int P, long long R, int width, int height, size_t* geometry, size_t* binning, size_t* image);
+
+/*
+ * Per-stage timing with HIP events recorded on the caller's stream around each
+ * stage of ngs_rasterize_forward / _backward.  No counterpart in the reference
+ * (its only timer is a torch.cuda.Event pair around a whole iteration,
+ * train.py:44-45,67,95).  One device per process; not thread-safe.
+ * ngs_profile_read synchronises with the recorded events and returns, per
+ * stage, the summed duration in ms and the number of timed launches since the
+ * last reset; both arrays hold ngs_profile_stage_count() entries.
+ */
+void ngs_profile_enable(int on);
+int ngs_profile_stage_count(void);
+const char* ngs_profile_stage_name(int stage);
+int ngs_profile_read(double* total_ms, long long* launches, int reset);
 
 /* Message of the last failure on the calling thread ("" if none). */
 const char* ngs_last_error(void);

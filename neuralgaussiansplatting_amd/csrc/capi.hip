@@ -31,6 +31,97 @@ static int fail(const char* what, const char* detail)
         if (e_ != hipSuccess) return fail("stage " name, hipGetErrorString(e_));       \
     } while (0)
 
+// ---------------------------------------------------------------------------
+// Optional per-stage timing with HIP events recorded on the caller's stream
+// (what a benchmark needs to quote a kernel's duration without a profiler).
+// A ring of event sets lets many calls be in flight; totals are harvested when
+// a slot is reused and when the caller reads them.
+// ---------------------------------------------------------------------------
+enum {
+    ST_PREPROCESS, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD,
+    ST_BWD_ZERO, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT
+};
+static const char* const g_stage_names[ST_COUNT] = {
+    "preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort", "tile_ranges", "render_fwd",
+    "zero_accumulator", "render_bwd", "preprocess_bwd"};
+#define PROF_RING 32
+struct ProfSlot {
+    hipEvent_t ev[ST_COUNT][2];
+    bool used[ST_COUNT];
+};
+static struct {
+    bool enabled, created;
+    ProfSlot ring[PROF_RING];
+    unsigned next;
+    double total_ms[ST_COUNT];
+    long long count[ST_COUNT];
+} g_prof;
+
+static void prof_harvest(ProfSlot& s)
+{
+    for (int i = 0; i < ST_COUNT; i++) {
+        if (!s.used[i]) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(s.ev[i][1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, s.ev[i][0], s.ev[i][1]) == hipSuccess) {
+            g_prof.total_ms[i] += ms;
+            g_prof.count[i]++;
+        }
+        s.used[i] = false;
+    }
+}
+
+static int prof_acquire()
+{
+    if (!g_prof.enabled) return -1;
+    if (!g_prof.created) {
+        for (int r = 0; r < PROF_RING; r++)
+            for (int i = 0; i < ST_COUNT; i++) {
+                g_prof.ring[r].used[i] = false;
+                for (int k = 0; k < 2; k++)
+                    if (hipEventCreate(&g_prof.ring[r].ev[i][k]) != hipSuccess) return -1;
+            }
+        g_prof.created = true;
+    }
+    const int slot = (int)(g_prof.next++ % PROF_RING);
+    prof_harvest(g_prof.ring[slot]);
+    return slot;
+}
+
+static inline void prof_begin(int slot, int stage, hipStream_t st)
+{
+    if (slot >= 0) (void)hipEventRecord(g_prof.ring[slot].ev[stage][0], st);
+}
+
+static inline void prof_end(int slot, int stage, hipStream_t st)
+{
+    if (slot >= 0) {
+        (void)hipEventRecord(g_prof.ring[slot].ev[stage][1], st);
+        g_prof.ring[slot].used[stage] = true;
+    }
+}
+
+extern "C" void ngs_profile_enable(int on) { g_prof.enabled = on != 0; }
+
+extern "C" int ngs_profile_stage_count(void) { return ST_COUNT; }
+
+extern "C" const char* ngs_profile_stage_name(int stage)
+{
+    return stage >= 0 && stage < ST_COUNT ? g_stage_names[stage] : "";
+}
+
+extern "C" int ngs_profile_read(double* total_ms, long long* launches, int reset)
+{
+    if (g_prof.created)
+        for (int r = 0; r < PROF_RING; r++) prof_harvest(g_prof.ring[r]);
+    for (int i = 0; i < ST_COUNT; i++) {
+        if (total_ms) total_ms[i] = g_prof.total_ms[i];
+        if (launches) launches[i] = g_prof.count[i];
+        if (reset) { g_prof.total_ms[i] = 0.0; g_prof.count[i] = 0; }
+    }
+    return ST_COUNT;
+}
+
 // rasterizer_impl.cu:35-50
 static uint32_t higher_msb(uint32_t n)
 {
@@ -129,12 +220,17 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     if (!radii) radii = (int*)(gb + gl.radii);
     const int nblocks = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
 
+    const int ps = prof_acquire();
     NGS_HIP(hipMemsetAsync(misc, 0, 32, st));
+    prof_begin(ps, ST_PREPROCESS, st);
     ngs_launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
                               colors_precomp, cam, prefiltered, radii, g0, g1, g2, depth, rect, tiles, clamped,
                               block_sums, misc);
+    prof_end(ps, ST_PREPROCESS, st);
     NGS_STAGE("preprocess");
+    prof_begin(ps, ST_SCAN, st);
     ngs_launch_scan_block_sums(st, nblocks, block_sums, block_offs, misc);
+    prof_end(ps, ST_SCAN, st);
     NGS_STAGE("scan");
 
     // The instance count sizes the binning buffer: one blocking 8-byte read-back.
@@ -159,16 +255,24 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     const int end_bit = 32 + (int)higher_msb((uint32_t)T);
     const int in_buf = ngs_sort_input_buffer(end_bit);
     if (R > 0) {
+        prof_begin(ps, ST_DUPLICATE, st);
         ngs_launch_duplicate(st, P, rect, depth, tiles, block_offs, cam.grid_x, keys[in_buf], vals[in_buf]);
+        prof_end(ps, ST_DUPLICATE, st);
         NGS_STAGE("duplicateWithKeys");
+        prof_begin(ps, ST_SORT, st);
         ngs_launch_sort_pairs(st, R, keys, vals, hist, totals, end_bit);
+        prof_end(ps, ST_SORT, st);
         NGS_STAGE("sort");
     }
     uint2* ranges = (uint2*)(ib + il.ranges);
+    prof_begin(ps, ST_RANGES, st);
     ngs_launch_tile_ranges(st, R, keys[0], T, ranges);
+    prof_end(ps, ST_RANGES, st);
     NGS_STAGE("identifyTileRanges");
+    prof_begin(ps, ST_RENDER_FWD, st);
     ngs_launch_render_fwd(st, cam, ranges, vals[0], g0, g1, g2, background, (float*)(ib + il.final_T),
                           (uint32_t*)(ib + il.n_contrib), out_color);
+    prof_end(ps, ST_RENDER_FWD, st);
     NGS_STAGE("render");
     return 0;
 }
@@ -204,18 +308,25 @@ extern "C" int ngs_rasterize_backward(int P, int D, int M, int R, const float* b
     if (!radii) radii = (const int*)(gb + gl.radii);
     float* acc = (float*)(gb + gl.acc);
 
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_BWD_ZERO, st);
     NGS_HIP(hipMemsetAsync(acc, 0, (size_t)P * NGS_ACC_STRIDE * sizeof(float), st));
+    prof_end(ps, ST_BWD_ZERO, st);
+    prof_begin(ps, ST_RENDER_BWD, st);
     ngs_launch_render_bwd(st, cam, (const uint2*)(ib + il.ranges), (const uint32_t*)(bb + bl.vals[0]),
                           (const float4*)(gb + gl.g0), (const float4*)(gb + gl.g1), (const float*)(gb + gl.g2),
                           background, (const float*)(ib + il.final_T), (const uint32_t*)(ib + il.n_contrib), dL_dpix,
                           acc);
+    prof_end(ps, ST_RENDER_BWD, st);
     NGS_STAGE("render backward");
+    prof_begin(ps, ST_PREPROCESS_BWD, st);
     // scales == NULL (precomputed covariance) skips the scale/rotation gradients, shs == NULL the SH ones,
     // as in the reference (backward.cu:390-395).
     ngs_launch_preprocess_bwd(st, P, D, M, means3D, radii, shs, (const uint8_t*)(gb + gl.clamped),
                               cov3D_precomp ? nullptr : scales, rotations, scale_modifier, cov3D_precomp, cam, acc,
                               dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                               dL_drot);
+    prof_end(ps, ST_PREPROCESS_BWD, st);
     NGS_STAGE("preprocess backward");
     return 0;
 }

@@ -1,0 +1,40 @@
+"""Decode the rasterizer's three opaque state buffers into reference-shaped
+numpy arrays (inspection, parity tests and benchmark statistics only; the
+layout comes from ``ngs_state_layout`` in include/ngs_rasterizer.h)."""
+import numpy as np
+
+
+def _view(buf, off, dtype, count):
+    """numpy view of `count` items of `dtype` at byte offset `off` past the 256-aligned base of a CUDA byte tensor."""
+    base = buf.data_ptr()
+    aligned = (base + 255) // 256 * 256
+    start = aligned - base + off
+    nbytes = count * np.dtype(dtype).itemsize
+    return buf[start:start + nbytes].cpu().numpy().view(dtype)
+
+
+def decode_state(_C, P, R, W, H, geom, binning, img):
+    """Unpack the HIP library's three state buffers into reference-shaped numpy arrays."""
+    gl, bl, il = _C.state_layout(P, R, W, H)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    a = _view(geom, gl["xy_conicab"], np.float32, 4 * P).reshape(P, 4)
+    b = _view(geom, gl["conicc_opacity_rg"], np.float32, 4 * P).reshape(P, 4)
+    c = _view(geom, gl["blue"], np.float32, P)
+    out = dict(
+        means2D=a[:, :2].copy(),
+        conic_opacity=np.stack([a[:, 2], a[:, 3], b[:, 0], b[:, 1]], axis=1),
+        rgb=np.stack([b[:, 2], b[:, 3], c], axis=1),
+        depths=_view(geom, gl["depth"], np.float32, P),
+        tile_rect=_view(geom, gl["tile_rect"], np.uint32, 2 * P).reshape(P, 2),
+        tiles_touched=_view(geom, gl["tiles_touched"], np.uint32, P),
+        clamped_bits=_view(geom, gl["clamped_bits"], np.uint8, P),
+        keys_sorted=_view(binning, bl["sorted_keys"], np.uint64, R),
+        point_list=_view(binning, bl["point_list"], np.uint32, R),
+        ranges=_view(img, il["ranges"], np.uint32, 2 * T).reshape(T, 2),
+    )
+    ft = _view(img, il["final_T"], np.float32, T * 256).reshape(gy, gx, 16, 16)
+    nc = _view(img, il["n_contrib"], np.uint32, T * 256).reshape(gy, gx, 16, 16)
+    out["final_T"] = ft.transpose(0, 2, 1, 3).reshape(gy * 16, gx * 16)[:H, :W]
+    out["n_contrib"] = nc.transpose(0, 2, 1, 3).reshape(gy * 16, gx * 16)[:H, :W]
+    return out

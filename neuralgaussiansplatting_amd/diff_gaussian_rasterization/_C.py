@@ -118,9 +118,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 return_conic=False):
+                                 return_conic=False, out=None):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
-    (rasterize_points.cu:195); with ``return_conic`` a ninth element dL_dconic [P,2,2] is appended."""
+    (rasterize_points.cu:195); with ``return_conic`` a ninth element dL_dconic [P,2,2] is appended.
+    ``out`` may map any of those names to a preallocated contiguous float32 tensor of the right size (for
+    instance a slice of one flat gradient bucket that is all-reduced afterwards); the rest are allocated here."""
     _require_gpu(means3D)
     dev = means3D.device
     P = means3D.size(0)
@@ -130,17 +132,28 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         _f32(x, dev) for x in (means3D, colors, scales, rotations, cov3D_precomp, sh, dL_dout_color))
     background, viewmatrix, projmatrix, campos = (_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
     # The library writes every element of every output, so no zero fill is needed when P > 0.
-    mk = torch.empty if P != 0 else torch.zeros
-    opts = dict(dtype=torch.float32, device=dev)
-    dL_dmeans3D = mk((P, 3), **opts)
-    dL_dmeans2D = mk((P, 3), **opts)
-    dL_dcolors = mk((P, NUM_CHANNELS), **opts)
-    dL_dconic = mk((P, 2, 2), **opts) if return_conic else None
-    dL_dopacity = mk((P, 1), **opts)
-    dL_dcov3D = mk((P, 6), **opts)
-    dL_dsh = mk((P, M, 3), **opts)
-    dL_dscales = mk((P, 3), **opts)
-    dL_drotations = mk((P, 4), **opts)
+    out = out or {}
+
+    def mk(name, shape):
+        t = out.get(name)
+        if t is None:
+            return (torch.empty if P != 0 else torch.zeros)(shape, dtype=torch.float32, device=dev)
+        n = 1
+        for d in shape:
+            n *= d
+        if t.numel() != n or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+            raise RuntimeError("out[%r] must be a contiguous float32 tensor with %d elements on %s" % (name, n, dev))
+        return t.view(shape)
+
+    dL_dmeans3D = mk("dL_dmeans3D", (P, 3))
+    dL_dmeans2D = mk("dL_dmeans2D", (P, 3))
+    dL_dcolors = mk("dL_dcolors", (P, NUM_CHANNELS))
+    dL_dconic = mk("dL_dconic", (P, 2, 2)) if return_conic else None
+    dL_dopacity = mk("dL_dopacity", (P, 1))
+    dL_dcov3D = mk("dL_dcov3D", (P, 6))
+    dL_dsh = mk("dL_dsh", (P, M, 3))
+    dL_dscales = mk("dL_dscales", (P, 3))
+    dL_drotations = mk("dL_drotations", (P, 4))
     if P != 0:
         with torch.cuda.device(dev):
             _check(lib().ngs_rasterize_backward(
@@ -151,8 +164,24 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors),
                 _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
                 int(bool(debug)), _stream(dev)))
-    out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
-    return out + (dL_dconic,) if return_conic else out
+    res = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    return res + (dL_dconic,) if return_conic else res
+
+
+def profile_enable(on=True):
+    """Time every stage with HIP events on the launch stream (see ngs_profile_* in include/ngs_rasterizer.h)."""
+    lib().ngs_profile_enable(int(bool(on)))
+
+
+def profile_read(reset=True):
+    """-> {stage name: (total ms, timed launches)} since the last reset; waits for the recorded events."""
+    L = lib()
+    n = L.ngs_profile_stage_count()
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_longlong * n)()
+    L.ngs_profile_read(ms, cnt, int(bool(reset)))
+    L.ngs_profile_stage_name.restype = ctypes.c_char_p
+    return {L.ngs_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
