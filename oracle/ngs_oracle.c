@@ -266,6 +266,22 @@ int ngs_oracle_preprocess(int P, int D, int M, const float* means, const float* 
     return bad;
 }
 
+/* SH -> RGB alone, for every Gaussian (same code path as inside ngs_oracle_preprocess): lets the stage be
+ * checked against vectors produced by the reference's Python eval_sh (utils/sh_utils.py:57-112). */
+void ngs_oracle_sh_to_rgb(int P, int D, int M, const float* means, const float* campos, const float* shs, float* rgb,
+                          uint8_t* clamped)
+{
+    for (int i = 0; i < P; i++) {
+        const float* p = means + 3 * i;
+        v3 pos = {p[0], p[1], p[2]}, cam = {campos[0], campos[1], campos[2]};
+        v3 d = v3_sub(pos, cam);
+        float len = sqrtf(v3_dot(d, d));
+        d.x = d.x / len; d.y = d.y / len; d.z = d.z / len;
+        v3 col = sh_to_rgb(D, shs + (size_t)3 * M * i, d, clamped + 3 * i);
+        rgb[3 * i] = col.x; rgb[3 * i + 1] = col.y; rgb[3 * i + 2] = col.z;
+    }
+}
+
 /* dgr/cuda_rasterizer/rasterizer_impl.cu:54-66 */
 void ngs_oracle_mark_visible(int P, const float* means, const float* vm, const float* pm, uint8_t* present)
 {

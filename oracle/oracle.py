@@ -61,6 +61,16 @@ def higher_msb(n):
     return int(lib().ngs_oracle_higher_msb(ctypes.c_uint32(n)))
 
 
+def sh_to_rgb(deg, means3D, campos, shs):
+    """(rgb [P,3], clamped [P,3]) of the SH->RGB stage alone."""
+    means3D, campos, shs = _f32(means3D), _f32(campos), _f32(shs)
+    P, M = shs.shape[0], shs.shape[1]
+    rgb = np.zeros((P, 3), np.float32)
+    cl = np.zeros((P, 3), np.uint8)
+    lib().ngs_oracle_sh_to_rgb(P, int(deg), M, _p(means3D), _p(campos), _p(shs), _p(rgb), _p(cl))
+    return rgb, cl
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     means3D = _f32(means3D)
     P = means3D.shape[0]

@@ -1,0 +1,79 @@
+"""Generates tests/golden/*.npz from the reference's own importable Python.
+
+Run in the build container only (it imports from /root/reference, which does
+not exist on the GPU box):  python tests/golden/make_golden.py
+
+The reference ships no tests or golden vectors for the rasterizer, and its
+CUDA sources cannot be built here, so these fixtures pin what its Python can
+pin: SH -> RGB (utils/sh_utils.py:57-112, the function behind the
+``convert_SHs_python`` switch, gaussian_renderer/__init__.py:74-79), the
+camera matrices (utils/graphics_utils.py:38-71 combined as in
+scene/cameras.py:54-57) and the training loss terms (utils/loss_utils.py:17-63).
+Only inputs and outputs are stored.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "/root/reference")
+from utils.graphics_utils import getProjectionMatrix, getWorld2View2  # noqa: E402
+from utils.loss_utils import l1_loss, ssim  # noqa: E402
+from utils.sh_utils import eval_sh  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def sh_fixture():
+    g = torch.Generator().manual_seed(2024)
+    P = 97
+    means = (torch.rand(P, 3, generator=g) * 2 - 1) * 1.5
+    campos = torch.tensor([0.3, -0.2, -3.5])
+    shs = torch.randn(P, 16, 3, generator=g) * 2.0  # [P, M, 3] as the rasterizer takes them; large enough to clamp
+    out = {"means": means.numpy(), "campos": campos.numpy(), "shs": shs.numpy()}
+    dirs = means - campos
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    for deg in range(4):
+        rgb = eval_sh(deg, shs.transpose(1, 2), dirs)  # reference layout [P, 3, M]
+        out["rgb_deg%d" % deg] = torch.clamp_min(rgb + 0.5, 0.0).numpy()
+        out["raw_deg%d" % deg] = (rgb + 0.5).numpy()
+    np.savez(os.path.join(HERE, "sh_to_rgb.npz"), **out)
+
+
+def camera_fixture():
+    out = {}
+    rng = np.random.RandomState(7)
+    for i in range(4):
+        # a random rotation (QR) and translation, FoVs in the range the datasets use
+        q, _ = np.linalg.qr(rng.randn(3, 3))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        t = rng.randn(3) * 2.0
+        fovx, fovy = 0.5 + 0.2 * i, 0.35 + 0.15 * i
+        view_t = torch.tensor(getWorld2View2(q, t, np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
+        proj_t = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+        full = view_t.unsqueeze(0).bmm(proj_t.unsqueeze(0)).squeeze(0)
+        out["R%d" % i], out["t%d" % i] = q, t
+        out["fov%d" % i] = np.array([fovx, fovy])
+        out["view_t%d" % i] = view_t.numpy()
+        out["proj_t%d" % i] = proj_t.numpy()
+        out["full%d" % i] = full.numpy()
+        out["campos%d" % i] = view_t.inverse()[3, :3].numpy()
+    np.savez(os.path.join(HERE, "camera_matrices.npz"), **out)
+
+
+def loss_fixture():
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(3, 40, 56, generator=g)
+    b = (a + 0.1 * torch.randn(3, 40, 56, generator=g)).clamp(0, 1)
+    np.savez(os.path.join(HERE, "loss_terms.npz"), img_a=a.numpy(), img_b=b.numpy(),
+             l1=np.float64(l1_loss(a, b).item()), ssim=np.float64(ssim(a, b).item()))
+
+
+if __name__ == "__main__":
+    sh_fixture()
+    camera_fixture()
+    loss_fixture()
+    print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
