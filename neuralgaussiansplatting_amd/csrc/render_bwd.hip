@@ -1,13 +1,58 @@
 // Per-tile back-to-front compositing gradient.  Same tiling and LDS staging
 // as the forward kernel, traversed in reverse; per-pixel arithmetic follows
-// cuda_rasterizer/backward.cu:399-557 of the reference.  What differs is the
-// reduction: the reference issues nine global float atomics per (pixel,
-// splat) pair.  Here all 64 lanes of a wave handle the same splat in
-// lock-step, so the nine partials are first summed across the wave by DPP,
-// then across the tile's four waves in an LDS table holding one row per
-// staged splat, and each splat's row leaves the workgroup once per batch as
-// ONE 64-byte-row group of global atomics into the [P][16] accumulator.
-#include "ngs_common.h"
+// cuda_rasterizer/backward.cu:399-557 of the reference.  What differs:
+//
+//  * The traversal starts at the tile's deepest contributor (the maximum of
+//    the per-pixel last-contributor indices the forward pass stored) instead
+//    of at the end of the tile's list: entries behind it are skipped by every
+//    pixel in the reference too (backward.cu:486-488), so they are never staged.
+//  * Each wave ballots which staged splats can reach its 16x4 strip AND lie in
+//    front of the strip's own deepest contributor, and walks only those.
+//  * Reduction: the reference issues nine global float atomics per (pixel,
+//    splat) pair.  Here all 64 lanes of a wave handle the same splat in
+//    lock-step, so the nine partials are summed across the wave in registers
+//    (lane-half / row swaps + DPP row shifts, a reduce-scatter), then
+//    across the tile's four waves in an LDS table holding one row per staged
+//    splat, and each splat's row leaves the workgroup once per batch as ONE
+//    64-byte-row group of global atomics into the [P][16] accumulator.
+#include "render_common.h"
+
+// [a summed over lane pairs (l, l+32) in lanes 0-31 | b likewise in lanes 32-63]
+__device__ __forceinline__ float fold32(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                                                    false, false);
+    unsigned x = r[0], y = r[1];
+    // hipcc (ROCm 7.2) folds "r[0] + r[1]" of a lane swap into "r[0] + r[0]"; an opaque use of the second result
+    // keeps the two registers apart.
+    asm volatile("" : "+v"(y));
+    return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+
+// rows 0,2: a summed over row pairs (0,1) / (2,3); rows 1,3: b likewise
+__device__ __forceinline__ float fold16(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                                                    false, false);
+    unsigned x = r[0], y = r[1];
+    // hipcc (ROCm 7.2) folds "r[0] + r[1]" of a lane swap into "r[0] + r[0]"; an opaque use of the second result
+    // keeps the two registers apart.
+    asm volatile("" : "+v"(y));
+    return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+
+// Sum over each 16-lane row; valid in lane 15 of the row.
+__device__ __forceinline__ float row_sum_lane15(float v)
+{
+#define NGS_ROW_ADD(ctrl) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    NGS_ROW_ADD(0x111);  // row_shr:1
+    NGS_ROW_ADD(0x112);  // row_shr:2
+    NGS_ROW_ADD(0x114);  // row_shr:4
+    NGS_ROW_ADD(0x118);  // row_shr:8
+#undef NGS_ROW_ADD
+    return v;
+}
 
 __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
@@ -15,26 +60,33 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ acc)
 {
-    __shared__ float4 s_a[NGS_TILE_PIX];  // x, y, conic a, conic b
-    __shared__ float4 s_b[NGS_TILE_PIX];  // conic c, opacity, r, g
-    __shared__ float s_c[NGS_TILE_PIX];   // b
-    __shared__ uint32_t s_id[NGS_TILE_PIX];
+    // record k: [0] = {x, y, reach x, reach y}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
+    __shared__ float4 s_rec[NGS_TILE_PIX][3];
     __shared__ float s_acc[NGS_TILE_PIX][ACC_USED];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ uint32_t s_wmax[NGS_TILE_PIX / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int px = tx * NGS_TILE_W + (tid & 15), py = ty * NGS_TILE_H + (tid >> 4);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    const float sx0 = (float)(tx * NGS_TILE_W), sx1 = sx0 + (NGS_TILE_W - 1);
+    const float sy0 = (float)(ty * NGS_TILE_H + wave * 4), sy1 = sy0 + 3.0f;
     const uint2 range = ranges[tile];
-    int todo = (int)(range.y - range.x);
-    const int rounds = (todo + NGS_TILE_PIX - 1) / NGS_TILE_PIX;
 
     const size_t tp = (size_t)tile * NGS_TILE_PIX + tid;
     const float T_final = inside ? final_T[tp] : 0.0f;
     float T = T_final;
-    uint32_t contributor = (uint32_t)todo;
     const uint32_t last_contributor = inside ? n_contrib[tp] : 0u;
+    // deepest contributor of this strip (wave) and of the tile
+    uint32_t wmax = last_contributor;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o, 64));
+    if (lane == 0) s_wmax[wave] = wmax;
+    __syncthreads();
+    const uint32_t tmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    if (tmax == 0) return;  // nothing in this tile was blended (block-uniform)
+
     float dpr = 0.0f, dpg = 0.0f, dpb = 0.0f;
     if (inside) {
         const size_t pid = (size_t)W * py + px, plane = (size_t)W * H;
@@ -48,88 +100,108 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     bgdot += bg[2] * dpb;
     float rec_r = 0.0f, rec_g = 0.0f, rec_b = 0.0f, last_r = 0.0f, last_g = 0.0f, last_b = 0.0f, last_alpha = 0.0f;
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    // accumulator slots this lane's 16-lane row ends up holding after the reduce-scatter below
+    const int lrow = lane >> 4;
+    const int slot0 = lrow == 0 ? ACC_DX : lrow == 1 ? ACC_CON_B : lrow == 2 ? ACC_OPAC : ACC_B;
+    const int slot1 = lrow == 0 ? ACC_DY : lrow == 1 ? ACC_CON_C : lrow == 2 ? ACC_R : -1;
+    const int slot2 = lrow == 0 ? ACC_CON_A : lrow == 2 ? ACC_G : -1;
 
-    for (int r = 0; r < rounds; r++, todo -= NGS_TILE_PIX) {
+    // Zero-based list positions tmax-1 ... 0 are walked in that order, 256 per batch;
+    // staged slot s of batch r holds list position tmax-1 - r*256 - s.
+    const int rounds = (int)((tmax + NGS_TILE_PIX - 1) / NGS_TILE_PIX);
+    for (int r = 0; r < rounds; r++) {
         __syncthreads();  // previous batch fully flushed before its LDS is reused
-        const uint32_t prog = (uint32_t)(r * NGS_TILE_PIX + tid);
-        if (range.x + prog < range.y) {
-            const uint32_t id = plist[range.y - prog - 1];
-            s_id[tid] = id;
-            s_a[tid] = g0[id];
-            s_b[tid] = g1[id];
-            s_c[tid] = g2[id];
+        const int first = (int)tmax - 1 - r * NGS_TILE_PIX;  // list position of slot 0
+        const int nb = min(NGS_TILE_PIX, first + 1);
+        if (tid < nb) {
+            const uint32_t id = plist[range.x + (uint32_t)(first - tid)];
+            const float4 a = g0[id];
+            const float4 b = g1[id];
+            const float c = g2[id];
+            const float2 h = splat_half_extent(a.z, a.w, b.x, b.y);
+            s_rec[tid][0] = make_float4(a.x, a.y, h.x, h.y);
+            s_rec[tid][1] = make_float4(a.z, a.w, b.x, b.y);
+            s_rec[tid][2] = make_float4(b.z, b.w, c, __uint_as_float(id));
         }
 #pragma unroll
         for (int c = 0; c < ACC_USED; c++) s_acc[tid][c] = 0.0f;
         __syncthreads();
-        const int nb = min(NGS_TILE_PIX, todo);
-        // Every lane of the wave walks the whole batch (no per-lane early exit:
-        // the wave-level reductions below need all 64 lanes present).
-        for (int j = 0; j < nb; j++) {
-            contributor--;
-            bool live = inside && contributor < last_contributor;
-            const float4 a = s_a[j];
-            const float4 b = s_b[j];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            live = live && !(power > 0.0f);
-            const float G = expf(power);
-            const float alpha = fminf(0.99f, b.y * G);
-            live = live && !(alpha < 1.0f / 255.0f);
-            if (__ballot(live) == 0ull) continue;  // wave-uniform: nobody in this 16x4 strip is touched
-
-            float v_dx = 0.0f, v_dy = 0.0f, v_ca = 0.0f, v_cb = 0.0f, v_cc = 0.0f, v_op = 0.0f, v_r = 0.0f,
-                  v_g = 0.0f, v_b = 0.0f;
-            if (live) {
-                T = T / (1.f - alpha);
-                const float w = alpha * T;
-                const float cr = b.z, cg = b.w, cb = s_c[j];
-                float dL_dalpha = 0.0f;
-                rec_r = last_alpha * last_r + (1.f - last_alpha) * rec_r;
-                last_r = cr;
-                dL_dalpha += (cr - rec_r) * dpr;
-                v_r = w * dpr;
-                rec_g = last_alpha * last_g + (1.f - last_alpha) * rec_g;
-                last_g = cg;
-                dL_dalpha += (cg - rec_g) * dpg;
-                v_g = w * dpg;
-                rec_b = last_alpha * last_b + (1.f - last_alpha) * rec_b;
-                last_b = cb;
-                dL_dalpha += (cb - rec_b) * dpb;
-                v_b = w * dpb;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;
-                const float dL_dG = b.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                v_dx = dL_dG * dG_ddelx * ddelx_dx;
-                v_dy = dL_dG * dG_ddely * ddely_dy;
-                v_ca = -0.5f * gdx * dx * dL_dG;
-                v_cb = -0.5f * gdx * dy * dL_dG;
-                v_cc = -0.5f * gdy * dy * dL_dG;
-                v_op = G * dL_dalpha;
+        for (int chunk = 0; chunk < nb; chunk += 64) {
+            const int mine = chunk + lane;
+            bool reach = false;
+            if (mine < nb && (uint32_t)(first - mine) < wmax) {
+                const float4 p = s_rec[mine][0];
+                reach = splat_touches(p.x, p.y, make_float2(p.z, p.w), sx0, sx1, sy0, sy1);
             }
-            v_dx = wave_sum_lane63(v_dx);
-            v_dy = wave_sum_lane63(v_dy);
-            v_ca = wave_sum_lane63(v_ca);
-            v_cb = wave_sum_lane63(v_cb);
-            v_cc = wave_sum_lane63(v_cc);
-            v_op = wave_sum_lane63(v_op);
-            v_r = wave_sum_lane63(v_r);
-            v_g = wave_sum_lane63(v_g);
-            v_b = wave_sum_lane63(v_b);
-            if (lane == 63) {
-                atomicAdd(&s_acc[j][ACC_DX], v_dx);
-                atomicAdd(&s_acc[j][ACC_DY], v_dy);
-                atomicAdd(&s_acc[j][ACC_CON_A], v_ca);
-                atomicAdd(&s_acc[j][ACC_CON_B], v_cb);
-                atomicAdd(&s_acc[j][ACC_CON_C], v_cc);
-                atomicAdd(&s_acc[j][ACC_OPAC], v_op);
-                atomicAdd(&s_acc[j][ACC_R], v_r);
-                atomicAdd(&s_acc[j][ACC_G], v_g);
-                atomicAdd(&s_acc[j][ACC_B], v_b);
+            unsigned long long mask = __ballot(reach);
+            while (mask) {
+                const int j = chunk + lowest_lane(mask);
+                mask &= mask - 1ull;
+                const uint32_t pos = (uint32_t)(first - j);  // the reference's `contributor` after its decrement
+                const float4 p = s_rec[j][0];
+                const float4 q = s_rec[j][1];
+                const float4 col = s_rec[j][2];
+                const float dx = p.x - pxf, dy = p.y - pyf;
+                const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
+                const float G = expf(power);
+                const float alpha = fminf(0.99f, q.w * G);
+                const bool live = pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(live) == 0ull) continue;  // wave-uniform
+
+                // Every lane evaluates the body; dead lanes keep their state and contribute exact zeros
+                // (their G and dL/dalpha are forced to 0, which zeroes every product below).
+                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32, 1 ulp
+                const float Tn = T * inv;
+                const float w = live ? alpha * Tn : 0.0f;
+                const float nrec_r = last_alpha * last_r + (1.f - last_alpha) * rec_r;
+                const float nrec_g = last_alpha * last_g + (1.f - last_alpha) * rec_g;
+                const float nrec_b = last_alpha * last_b + (1.f - last_alpha) * rec_b;
+                float dL_dalpha = 0.0f;
+                dL_dalpha += (col.x - nrec_r) * dpr;
+                dL_dalpha += (col.y - nrec_g) * dpg;
+                dL_dalpha += (col.z - nrec_b) * dpb;
+                dL_dalpha *= Tn;
+                dL_dalpha += (-T_final * inv) * bgdot;
+                dL_dalpha = live ? dL_dalpha : 0.0f;
+                const float Gl = live ? G : 0.0f;
+                const float dL_dG = q.w * dL_dalpha;
+                const float gdx = Gl * dx, gdy = Gl * dy;
+                const float dG_ddelx = -gdx * q.x - gdy * q.y;
+                const float dG_ddely = -gdy * q.z - gdx * q.y;
+                const float v0 = dL_dG * dG_ddelx * ddelx_dx;   // ACC_DX
+                const float v1 = dL_dG * dG_ddely * ddely_dy;   // ACC_DY
+                const float v2 = -0.5f * gdx * dx * dL_dG;      // ACC_CON_A
+                const float v3 = -0.5f * gdx * dy * dL_dG;      // ACC_CON_B
+                const float v4 = -0.5f * gdy * dy * dL_dG;      // ACC_CON_C
+                const float v5 = Gl * dL_dalpha;                // ACC_OPAC
+                const float v6 = w * dpr;                       // ACC_R
+                const float v7 = w * dpg;                       // ACC_G
+                const float v8 = w * dpb;                       // ACC_B
+                T = live ? Tn : T;
+                rec_r = live ? nrec_r : rec_r;
+                rec_g = live ? nrec_g : rec_g;
+                rec_b = live ? nrec_b : rec_b;
+                last_r = live ? col.x : last_r;
+                last_g = live ? col.y : last_g;
+                last_b = live ? col.z : last_b;
+                last_alpha = live ? alpha : last_alpha;
+
+                // Wave reduction of the nine partials as a reduce-scatter: two half/row swaps fold the 64 lanes
+                // into 16 columns while spreading the nine values over the four 16-lane rows of three registers,
+                // then one 4-step DPP row reduction per register leaves each value's total in lane 15 of its row.
+                //   s0 rows: [v0, v3, v5, v8]   s1 rows: [v1, v4, v6, -]   s2 rows: [v2, -, v7, -]
+                const float r0 = fold32(v0, v5), r1 = fold32(v1, v6), r2 = fold32(v2, v7), r3 = fold32(v3, v8),
+                            r4 = fold32(v4, 0.0f);
+                float s0 = fold16(r0, r3), s1 = fold16(r1, r4), s2 = fold16(r2, 0.0f);
+                s0 = row_sum_lane15(s0);
+                s1 = row_sum_lane15(s1);
+                s2 = row_sum_lane15(s2);
+                if ((lane & 15) == 15) {
+                    float* row = &s_acc[j][0];
+                    atomicAdd(row + slot0, s0);
+                    if (slot1 >= 0) atomicAdd(row + slot1, s1);
+                    if (slot2 >= 0) atomicAdd(row + slot2, s2);
+                }
             }
         }
         __syncthreads();
@@ -138,7 +210,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
         for (int j = tid >> 4; j < nb; j += NGS_TILE_PIX / 16) {
             if (c < ACC_USED) {
                 const float v = s_acc[j][c];
-                if (v != 0.0f) atomicAdd(acc + (size_t)s_id[j] * NGS_ACC_STRIDE + c, v);
+                if (v != 0.0f)
+                    atomicAdd(acc + (size_t)__float_as_uint(s_rec[j][2].w) * NGS_ACC_STRIDE + c, v);
             }
         }
     }

@@ -1,10 +1,16 @@
 // Per-tile front-to-back alpha compositing (forward).  One 256-thread
 // workgroup per 16x16 tile, four wave64s each covering a 16x4 pixel strip.
-// Batches of 256 depth-sorted splats are staged into LDS (position, conic,
-// opacity AND colour, so the inner loop never touches global memory) and every
-// lane walks the batch for its own pixel.  Per-pixel arithmetic and its order
-// follow cuda_rasterizer/forward.cu:261-374 of the reference.
-#include "ngs_common.h"
+// Batches of 256 depth-sorted splats are staged into LDS as 48-byte records
+// (position + reach, conic + opacity, colour), so the inner loop never touches
+// global memory.  Each wave then ballots, 64 splats at a time, which staged
+// splats can reach its strip at all (opacity-aware bounding box,
+// render_common.h) and walks only the set bits of that wave-uniform mask; the
+// other splats cost it nothing.  The per-pixel body is branch-free: one group
+// of three broadcast LDS reads, then predicated arithmetic.
+// Per-pixel arithmetic and its order follow cuda_rasterizer/forward.cu:261-374
+// of the reference; skipping a splat whose box misses the strip cannot change
+// any pixel because every pixel of the strip would have failed the alpha test.
+#include "render_common.h"
 
 __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
@@ -12,55 +18,72 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     float* __restrict__ out_color)
 {
-    __shared__ float4 s_a[NGS_TILE_PIX];  // x, y, conic a, conic b
-    __shared__ float4 s_b[NGS_TILE_PIX];  // conic c, opacity, r, g
-    __shared__ float s_c[NGS_TILE_PIX];   // b
-    const int tid = threadIdx.x;
+    // record k: [0] = {x, y, reach x, reach y}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, -}
+    __shared__ float4 s_rec[NGS_TILE_PIX][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int px = tx * NGS_TILE_W + (tid & 15), py = ty * NGS_TILE_H + (tid >> 4);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    // this wave's pixel strip
+    const float sx0 = (float)(tx * NGS_TILE_W), sx1 = sx0 + (NGS_TILE_W - 1);
+    const float sy0 = (float)(ty * NGS_TILE_H + wave * 4), sy1 = sy0 + 3.0f;
     const uint2 range = ranges[tile];
     int todo = (int)(range.y - range.x);
     const int rounds = (todo + NGS_TILE_PIX - 1) / NGS_TILE_PIX;
 
     bool done = !inside;
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
 
     for (int r = 0; r < rounds; r++, todo -= NGS_TILE_PIX) {
         if (__syncthreads_count(done) == NGS_TILE_PIX) break;
         const uint32_t src = range.x + r * NGS_TILE_PIX + tid;
         if (src < range.y) {
             const uint32_t id = plist[src];
-            s_a[tid] = g0[id];
-            s_b[tid] = g1[id];
-            s_c[tid] = g2[id];
+            const float4 a = g0[id];
+            const float4 b = g1[id];
+            const float c = g2[id];
+            const float2 h = splat_half_extent(a.z, a.w, b.x, b.y);
+            s_rec[tid][0] = make_float4(a.x, a.y, h.x, h.y);
+            s_rec[tid][1] = make_float4(a.z, a.w, b.x, b.y);
+            s_rec[tid][2] = make_float4(b.z, b.w, c, 0.0f);
         }
         __syncthreads();
         const int nb = min(NGS_TILE_PIX, todo);
-        for (int j = 0; !done && j < nb; j++) {
-            contributor++;
-            const float4 a = s_a[j];
-            const float4 b = s_b[j];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, b.y * expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1 - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
+        if (__ballot(!done) == 0ull) continue;  // this strip is finished; keep helping with the staging
+        const uint32_t base = (uint32_t)(r * NGS_TILE_PIX + 1);
+        for (int chunk = 0; chunk < nb; chunk += 64) {
+            const int mine = chunk + lane;
+            bool reach = false;
+            if (mine < nb) {
+                const float4 p = s_rec[mine][0];
+                reach = splat_touches(p.x, p.y, make_float2(p.z, p.w), sx0, sx1, sy0, sy1);
             }
-            const float w = alpha * T;
-            Cr += b.z * alpha * T;
-            Cg += b.w * alpha * T;
-            Cb += s_c[j] * alpha * T;
-            (void)w;
-            T = test_T;
-            last_contributor = contributor;
+            unsigned long long mask = __ballot(reach);
+            while (mask) {
+                const int j = chunk + lowest_lane(mask);
+                mask &= mask - 1ull;
+                const float4 p = s_rec[j][0];
+                const float4 q = s_rec[j][1];
+                const float4 c = s_rec[j][2];
+                const float dx = p.x - pxf, dy = p.y - pyf;
+                const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
+                const float alpha = fminf(0.99f, q.w * expf(power));
+                const float test_T = T * (1 - alpha);
+                const bool hit = !done && power <= 0.0f && !(alpha < 1.0f / 255.0f);
+                const bool stop = hit && test_T < 0.0001f;
+                const bool blend = hit && !stop;
+                done = done || stop;
+                Cr = blend ? Cr + c.x * alpha * T : Cr;
+                Cg = blend ? Cg + c.y * alpha * T : Cg;
+                Cb = blend ? Cb + c.z * alpha * T : Cb;
+                T = blend ? test_T : T;
+                last_contributor = blend ? base + (uint32_t)j : last_contributor;
+                if (__ballot(!done) == 0ull) break;
+            }
+            if (__ballot(!done) == 0ull) break;
         }
     }
     if (inside) {

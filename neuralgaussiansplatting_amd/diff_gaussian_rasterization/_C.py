@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libngs_rasterizer.so")
+# NGS_RASTERIZER_LIB selects another build of the same library (kernel experiments); default is the in-tree one.
+LIB_PATH = os.environ.get("NGS_RASTERIZER_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libngs_rasterizer.so")
 NUM_CHANNELS = 3  # cuda_rasterizer/config.h:15
 
 _ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
