@@ -37,14 +37,15 @@ def stage_bytes(P, R, W, H, D, M, vis):
     """Algorithmic HBM bytes of one launch of each stage (per-unit figures in DESIGN.md)."""
     c = (D + 1) ** 2
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    passes = (32 + T.bit_length() + 7) // 8  # bit_length(T) is the reference's getHigherMsb(T)
+    tile_passes = (T.bit_length() + 7) // 8  # bit_length(T) is the reference's getHigherMsb(T)
     vP = vis * P
     return {
         "preprocess_fwd": P * (12 + 8) + vP * (32 + 12 * c + 49),
         "scan_block_sums": 8 * ((P + 255) // 256),
         "duplicate_with_keys": 4 * P + 12 * vP + 12 * R,
-        "radix_sort": passes * 24 * R,
+        "radix_sort_tile_bits": tile_passes * 24 * R,
         "tile_ranges": 8 * R + 16 * T,
+        "segment_sort_depth": 24 * R + 8 * T,
         "render_fwd": 40 * R + 8 * T + 20 * W * H,
         "zero_accumulator": 64 * P,
         "render_bwd": 112 * R + 8 * T + 20 * W * H,

@@ -38,11 +38,12 @@ static int fail(const char* what, const char* detail)
 // a slot is reused and when the caller reads them.
 // ---------------------------------------------------------------------------
 enum {
-    ST_PREPROCESS, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD,
+    ST_PREPROCESS, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SEGSORT, ST_RENDER_FWD,
     ST_BWD_ZERO, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT
 };
 static const char* const g_stage_names[ST_COUNT] = {
-    "preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort", "tile_ranges", "render_fwd",
+    "preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort_tile_bits", "tile_ranges", "segment_sort_depth",
+    "render_fwd",
     "zero_accumulator", "render_bwd", "preprocess_bwd"};
 #define PROF_RING 32
 struct ProfSlot {
@@ -260,7 +261,7 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
         prof_end(ps, ST_DUPLICATE, st);
         NGS_STAGE("duplicateWithKeys");
         prof_begin(ps, ST_SORT, st);
-        ngs_launch_sort_pairs(st, R, keys, vals, hist, totals, end_bit);
+        ngs_launch_sort_tile_bits(st, R, keys, vals, hist, totals, end_bit);
         prof_end(ps, ST_SORT, st);
         NGS_STAGE("sort");
     }
@@ -269,6 +270,12 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     ngs_launch_tile_ranges(st, R, keys[0], T, ranges);
     prof_end(ps, ST_RANGES, st);
     NGS_STAGE("identifyTileRanges");
+    if (R > 0) {
+        prof_begin(ps, ST_SEGSORT, st);
+        ngs_launch_sort_segments(st, T, ranges, keys, vals);
+        prof_end(ps, ST_SEGSORT, st);
+        NGS_STAGE("sort (depth)");
+    }
     prof_begin(ps, ST_RENDER_FWD, st);
     ngs_launch_render_fwd(st, cam, ranges, vals[0], g0, g1, g2, background, (float*)(ib + il.final_T),
                           (uint32_t*)(ib + il.n_contrib), out_color);

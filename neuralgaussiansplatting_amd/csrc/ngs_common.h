@@ -57,7 +57,7 @@ struct BinLayout {
 static inline size_t ngs_align_up(size_t v) { return (v + NGS_ALIGN - 1) & ~(size_t)(NGS_ALIGN - 1); }
 
 #define NGS_SORT_THREADS 256
-#define NGS_SORT_ITEMS 8
+#define NGS_SORT_ITEMS 16
 #define NGS_SORT_TILE (NGS_SORT_THREADS * NGS_SORT_ITEMS)
 
 static inline GeomLayout ngs_geom_layout(size_t P)
@@ -138,11 +138,14 @@ void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* bloc
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const float* depth, const uint32_t* tiles,
                           const uint32_t* block_offs, int grid_x, uint64_t* keys, uint32_t* vals);
 void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint64_t* keys, int T, uint2* ranges);
-// radix_sort.hip: stable LSD sort on key bits [0,end_bit); result in keys[0]/vals[0]; returns the buffer index
-// (0 or 1) the unsorted input must have been written to.
+// radix_sort.hip: stable sort on key bits [0,end_bit) in two levels: global radix passes over the tile bits
+// (32..end_bit), result in keys[0]/vals[0], then, once the tile ranges are known, a per-tile sort on the 32 depth
+// bits.  ngs_sort_input_buffer returns the buffer index (0 or 1) the unsorted input must be written to.
 int ngs_sort_input_buffer(int end_bit);
-void ngs_launch_sort_pairs(hipStream_t s, int64_t R, uint64_t* const keys[2], uint32_t* const vals[2], uint32_t* hist,
-                           uint32_t* totals, int end_bit);
+void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint64_t* const keys[2], uint32_t* const vals[2],
+                               uint32_t* hist, uint32_t* totals, int end_bit);
+void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, uint64_t* const keys[2],
+                              uint32_t* const vals[2]);
 // render_fwd.hip
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* g0, const float4* g1, const float* g2, const float* bg, float* final_T,

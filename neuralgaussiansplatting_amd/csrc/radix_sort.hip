@@ -1,15 +1,27 @@
-// Stable least-significant-digit radix sort of (uint64 key, uint32 value)
-// pairs on key bits [0,end_bit), written for wave64: 8-bit digits, 2048 pairs
-// per workgroup, ballot-based ranking.  It produces the result the reference
-// obtains from cub::DeviceRadixSort::SortPairs
-// (cuda_rasterizer/rasterizer_impl.cu:303-308): keys ascending on the masked
-// bits, ties in input order.
+// Stable sort of (uint64 key, uint32 value) pairs on key bits [0,end_bit),
+// key = (tile << 32) | depth bits, written for wave64 without any library.
+// It produces the result the reference obtains from
+// cub::DeviceRadixSort::SortPairs (cuda_rasterizer/rasterizer_impl.cu:303-308):
+// keys ascending on the masked bits, ties in input order.
 //
-// Per pass: (1) per-workgroup digit histogram, stored digit-major; (2) one
-// workgroup per digit turns its row of the histogram into exclusive prefixes
-// and records the digit total; (3) scatter: ranks pairs inside the workgroup in
-// input order, reorders them through LDS so that each digit's run leaves as
-// contiguous stores, and writes them at digit base + workgroup prefix + rank.
+// Two levels, exploiting the key's structure instead of running
+// ceil(end_bit/8) global passes:
+//
+//  1. Global LSD radix passes over the TILE bits only (bits 32..end_bit, one
+//     or two 8-bit passes).  Per pass: per-workgroup digit histogram (stored
+//     digit-major), one workgroup per digit turning its histogram row into
+//     exclusive prefixes, and a scatter that ranks pairs inside the workgroup
+//     in input order with wave ballots, reorders them through LDS so each
+//     digit's run leaves as contiguous stores, and writes them at
+//     digit base + workgroup prefix + rank.  Afterwards every tile's pairs are
+//     contiguous and still in emission order.
+//  2. One workgroup per tile sorts its segment by the 32 depth bits, stably,
+//     entirely in registers + LDS (four 8-bit passes, passes whose digit is
+//     constant over the segment are skipped); segments longer than 4096 pairs
+//     fall back to the same passes ping-ponging through the spare global buffer.
+//
+// Sorting stably by depth inside groups that are ordered by tile gives exactly
+// the order of a stable sort on (tile, depth).
 #include "ngs_common.h"
 
 #define ST NGS_SORT_THREADS
@@ -20,6 +32,25 @@
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, uint32_t mask)
 {
     return (uint32_t)(key >> shift) & mask;
+}
+
+// Rank of this lane's item among the wave's items with the same digit that come earlier in input order, plus
+// the number of such items in earlier rounds (kept in cnt[digit]); updates cnt.  All 64 lanes must call it.
+__device__ __forceinline__ uint32_t wave_rank(uint32_t d, bool valid, uint32_t* cnt, uint64_t lanes_below)
+{
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    const uint32_t before = cnt[d];
+    const uint32_t rank = before + (uint32_t)__popcll(peers & lanes_below);
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (peers & lanes_below) == 0) cnt[d] = before + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    return rank;
 }
 
 __global__ __launch_bounds__(ST) void sort_hist_kernel(int64_t n, const uint64_t* __restrict__ keys, int shift,
@@ -42,29 +73,34 @@ __global__ __launch_bounds__(ST) void sort_hist_kernel(int64_t n, const uint64_t
 }
 
 // Workgroup d: exclusive prefix over hist[d][0..nblocks) in place, total to totals[d].
-__global__ __launch_bounds__(256) void sort_scan_kernel(int nblocks, uint32_t* __restrict__ hist,
-                                                        uint32_t* __restrict__ totals)
+// Thread t owns a contiguous run of ceil(nblocks/1024) entries.
+#define SCAN_T 1024
+__global__ __launch_bounds__(SCAN_T) void sort_scan_kernel(int nblocks, uint32_t* __restrict__ hist,
+                                                           uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t wave_tot[4];
-    __shared__ uint32_t s_carry;
+    __shared__ uint32_t wave_tot[SCAN_T / 64];
     uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
+    const int per = (nblocks + SCAN_T - 1) / SCAN_T;
+    const int lo = tid * per, hi = min(nblocks, lo + per);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += row[i];
+    const uint32_t incl = wave_incl_scan_u32(s, lane);
+    if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    for (int start = 0; start < nblocks; start += 256) {
-        const int i = start + tid;
-        const uint32_t v = i < nblocks ? row[i] : 0u;
-        const uint32_t incl = wave_incl_scan_u32(v, lane);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t base = s_carry;
-        for (int w = 0; w < wave; w++) base += wave_tot[w];
-        if (i < nblocks) row[i] = base + incl - v;
-        __syncthreads();
-        if (tid == 255) s_carry = base + incl;
-        __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < SCAN_T / 64; w++) {
+        const uint32_t t = wave_tot[w];
+        if (w < wave) base += t;
+        total += t;
     }
-    if (tid == 0) totals[blockIdx.x] = s_carry;
+    uint32_t run = base + incl - s;
+    for (int i = lo; i < hi; i++) {
+        const uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (tid == 0) totals[blockIdx.x] = total;
 }
 
 __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint64_t* __restrict__ kin,
@@ -78,6 +114,7 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint6
     __shared__ uint32_t s_start[256];        // first local slot of each digit
     __shared__ uint32_t s_gofs[256];         // global position of local slot 0 of each digit (minus s_start)
     __shared__ uint32_t s_wtot[SWAVES];
+    __shared__ uint32_t s_gwtot[SWAVES];
     __shared__ uint64_t s_key[STILE];
     __shared__ uint32_t s_val[STILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,8 +123,8 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint6
     for (int w = 0; w < SWAVES; w++) s_cnt[w][tid] = 0;
     __syncthreads();
 
-    // Wave-striped ownership keeps input order: wave w owns slots [w*512, w*512+512), item i of lane l is slot
-    // w*512 + i*64 + l.
+    // Wave-striped ownership keeps input order: wave w owns slots [w*64*SI, (w+1)*64*SI), item i of lane l is
+    // slot w*64*SI + i*64 + l.
     uint64_t key[SI];
     uint32_t val[SI], rank[SI];
     const uint64_t lanes_below = (1ull << lane) - 1ull;
@@ -101,20 +138,7 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint6
 #pragma unroll
     for (int i = 0; i < SI; i++) {
         const int slot = wave * (64 * SI) + i * 64 + lane;
-        const bool valid = slot < n_valid;
-        const uint32_t d = digit_of(key[i], shift, mask);
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const uint32_t before = s_cnt[wave][d];
-        rank[i] = before + (uint32_t)__popcll(peers & lanes_below);
-        __builtin_amdgcn_wave_barrier();
-        if (valid && (peers & lanes_below) == 0) s_cnt[wave][d] = before + (uint32_t)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
+        rank[i] = wave_rank(digit_of(key[i], shift, mask), slot < n_valid, s_cnt[wave], lanes_below);
     }
     __syncthreads();
 
@@ -129,7 +153,6 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint6
     // The same pattern scans the global digit totals to get each digit's base in the output.
     const uint32_t gtot = totals[tid];
     const uint32_t gincl = wave_incl_scan_u32(gtot, lane);
-    __shared__ uint32_t s_gwtot[SWAVES];
     if (lane == 63) { s_wtot[wave] = incl; s_gwtot[wave] = gincl; }
     __syncthreads();
     uint32_t lbase = 0, gbase = 0;
@@ -162,23 +185,215 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint6
     }
 }
 
-static int sort_passes(int end_bit) { return (end_bit + 7) / 8; }
+// ---------------------------------------------------------------------------
+// Level 2: per-tile stable sort by the low 32 key bits.
+// ---------------------------------------------------------------------------
+// One 8-bit pass over the (up to 256*ITEMS) items a workgroup holds in registers: ranks them stably by digit and
+// returns each item's position among the workgroup's items; tot_out = items with digit `tid` in the workgroup.
+// `quota` = slots owned by each wave (multiple of 64); item i of lane l of wave w is slot w*quota + i*64 + l.
+template <int ITEMS>
+__device__ __forceinline__ void block_rank_pass(const uint32_t (&key)[ITEMS], int shift, int n_valid, int quota,
+                                                uint32_t (*s_cnt)[256], uint32_t* s_start, uint32_t* s_wtot,
+                                                uint32_t (&pos)[ITEMS], uint32_t& tot_out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    for (int w = 0; w < SWAVES; w++) s_cnt[w][tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        if (i * 64 < quota) {  // wave-uniform
+            const int slot = wave * quota + i * 64 + lane;
+            pos[i] = wave_rank((key[i] >> shift) & 0xffu, slot < n_valid, s_cnt[wave], lanes_below);
+        }
+    }
+    __syncthreads();
+    uint32_t tot = 0;
+    for (int w = 0; w < SWAVES; w++) {
+        const uint32_t c = s_cnt[w][tid];
+        s_cnt[w][tid] = tot;
+        tot += c;
+    }
+    const uint32_t incl = wave_incl_scan_u32(tot, lane);
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    uint32_t lbase = 0;
+    for (int w = 0; w < wave; w++) lbase += s_wtot[w];
+    s_start[tid] = lbase + incl - tot;
+    tot_out = tot;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        if (i * 64 < quota) {
+            const uint32_t d = (key[i] >> shift) & 0xffu;
+            pos[i] += s_start[d] + s_cnt[wave][d];
+        }
+    }
+}
 
-int ngs_sort_input_buffer(int end_bit) { return sort_passes(end_bit) & 1; }
+// Segments with min_n < n <= 256*ITEMS: the whole segment lives in registers, no global traffic between passes.
+template <int ITEMS>
+__global__ __launch_bounds__(ST) void segment_sort_small_kernel(const uint2* __restrict__ ranges, int min_n,
+                                                                uint64_t* __restrict__ keys0,
+                                                                uint32_t* __restrict__ vals0)
+{
+    constexpr int CAP = ST * ITEMS;
+    __shared__ uint32_t s_cnt[SWAVES][256];
+    __shared__ uint32_t s_start[256];
+    __shared__ uint32_t s_wtot[SWAVES];
+    __shared__ uint32_t s_red[2 * SWAVES];
+    __shared__ uint32_t s_key[CAP];
+    __shared__ uint32_t s_val[CAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    if (n <= min_n || n > CAP) return;  // block-uniform: another launch (or nobody, n <= 1) owns this tile
+    const size_t lo = range.x;
+    const int quota = ((((n + SWAVES - 1) / SWAVES) + 63) / 64) * 64;  // slots per wave
+    uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
+    uint32_t k_or = 0u, k_and = ~0u;
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const int slot = wave * quota + i * 64 + lane;
+        const bool valid = i * 64 < quota && slot < n;
+        key[i] = valid ? (uint32_t)keys0[lo + slot] : ~0u;
+        val[i] = valid ? vals0[lo + slot] : 0u;
+        if (valid) { k_or |= key[i]; k_and &= key[i]; }
+    }
+    // bits that differ somewhere in the segment
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        k_or |= (uint32_t)__shfl_xor((int)k_or, o, 64);
+        k_and &= (uint32_t)__shfl_xor((int)k_and, o, 64);
+    }
+    if (lane == 0) { s_red[wave] = k_or; s_red[SWAVES + wave] = k_and; }
+    __syncthreads();
+    uint32_t varying;
+    {
+        uint32_t o = 0u, a = ~0u;
+        for (int w = 0; w < SWAVES; w++) { o |= s_red[w]; a &= s_red[SWAVES + w]; }
+        varying = o ^ a;
+    }
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (((varying >> shift) & 0xffu) == 0u) continue;  // digit constant over the segment (block-uniform)
+        uint32_t tot;
+        block_rank_pass<ITEMS>(key, shift, n, quota, s_cnt, s_start, s_wtot, pos, tot);
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int slot = wave * quota + i * 64 + lane;
+            if (i * 64 < quota && slot < n) { s_key[pos[i]] = key[i]; s_val[pos[i]] = val[i]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int slot = wave * quota + i * 64 + lane;
+            if (i * 64 < quota && slot < n) { key[i] = s_key[slot]; val[i] = s_val[slot]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const int slot = wave * quota + i * 64 + lane;
+        if (i * 64 < quota && slot < n) {
+            keys0[lo + slot] = ((uint64_t)tile << 32) | key[i];
+            vals0[lo + slot] = val[i];
+        }
+    }
+}
 
-void ngs_launch_sort_pairs(hipStream_t s, int64_t R, uint64_t* const keys[2], uint32_t* const vals[2], uint32_t* hist,
-                           uint32_t* totals, int end_bit)
+// Segments longer than STILE pairs: the same four passes, chunk by chunk, ping-ponging through the spare buffer.
+__global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __restrict__ ranges, uint64_t* keys0,
+                                                               uint32_t* vals0, uint64_t* keys1, uint32_t* vals1)
+{
+    __shared__ uint32_t s_cnt[SWAVES][256];
+    __shared__ uint32_t s_start[256];
+    __shared__ uint32_t s_base[256];
+    __shared__ uint32_t s_wtot[SWAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint2 range = ranges[blockIdx.x];
+    const int n = (int)(range.y - range.x);
+    if (n <= STILE) return;  // block-uniform
+    const size_t lo = range.x;
+    const int quota = 64 * SI;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = pass * 8;
+        const uint64_t* ksrc = (pass & 1) ? keys1 : keys0;
+        const uint32_t* vsrc = (pass & 1) ? vals1 : vals0;
+        uint64_t* kdst = (pass & 1) ? keys0 : keys1;
+        uint32_t* vdst = (pass & 1) ? vals0 : vals1;
+        __syncthreads();  // the previous pass's stores are visible to the whole workgroup
+        // digit histogram of the whole segment -> running digit bases
+        s_cnt[0][tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += ST) atomicAdd(&s_cnt[0][((uint32_t)ksrc[lo + i] >> shift) & 0xffu], 1u);
+        __syncthreads();
+        {
+            const uint32_t c = s_cnt[0][tid];
+            const uint32_t incl = wave_incl_scan_u32(c, lane);
+            if (lane == 63) s_wtot[wave] = incl;
+            __syncthreads();
+            uint32_t b = 0;
+            for (int w = 0; w < wave; w++) b += s_wtot[w];
+            s_base[tid] = b + incl - c;
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += STILE) {
+            const int m = min(STILE, n - c0);
+            uint32_t key[SI], pos[SI], val[SI];
+#pragma unroll
+            for (int i = 0; i < SI; i++) {
+                const int slot = wave * quota + i * 64 + lane;
+                const bool valid = slot < m;
+                key[i] = valid ? (uint32_t)ksrc[lo + c0 + slot] : ~0u;
+                val[i] = valid ? vsrc[lo + c0 + slot] : 0u;
+            }
+            uint32_t tot;
+            block_rank_pass<SI>(key, shift, m, quota, s_cnt, s_start, s_wtot, pos, tot);
+            // pos = rank inside the chunk ordered by digit; convert to the segment-wide position
+#pragma unroll
+            for (int i = 0; i < SI; i++) {
+                const int slot = wave * quota + i * 64 + lane;
+                if (slot < m) {
+                    const uint32_t d = (key[i] >> shift) & 0xffu;
+                    const uint32_t g = s_base[d] + (pos[i] - s_start[d]);
+                    kdst[lo + g] = ((uint64_t)blockIdx.x << 32) | key[i];
+                    vdst[lo + g] = val[i];
+                }
+            }
+            __syncthreads();
+            s_base[tid] += tot;
+            __syncthreads();
+        }
+    }
+}
+
+static int tile_passes(int end_bit) { return end_bit > 32 ? (end_bit - 32 + 7) / 8 : 0; }
+
+int ngs_sort_input_buffer(int end_bit) { return tile_passes(end_bit) & 1; }
+
+void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint64_t* const keys[2], uint32_t* const vals[2],
+                               uint32_t* hist, uint32_t* totals, int end_bit)
 {
     if (R <= 0) return;
     const int nblocks = (int)((R + STILE - 1) / STILE);
     int cur = ngs_sort_input_buffer(end_bit);
-    for (int shift = 0; shift < end_bit; shift += 8) {
+    for (int shift = 32; shift < end_bit; shift += 8) {
         const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
         const uint32_t mask = (1u << bits) - 1u;
         hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(ST), 0, s, R, keys[cur], shift, mask, nblocks, hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(256), 0, s, nblocks, hist, totals);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(SCAN_T), 0, s, nblocks, hist, totals);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(ST), 0, s, R, keys[cur], vals[cur], keys[cur ^ 1],
                            vals[cur ^ 1], shift, mask, nblocks, hist, totals);
         cur ^= 1;
     }
+}
+
+void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, uint64_t* const keys[2],
+                              uint32_t* const vals[2])
+{
+    // every tile is claimed by exactly one of the three launches (by segment length); the others exit at once
+    hipLaunchKernelGGL(segment_sort_small_kernel<8>, dim3(T), dim3(ST), 0, s, ranges, 1, keys[0], vals[0]);
+    hipLaunchKernelGGL(segment_sort_small_kernel<SI>, dim3(T), dim3(ST), 0, s, ranges, ST * 8, keys[0], vals[0]);
+    hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T), dim3(ST), 0, s, ranges, keys[0], vals[0], keys[1], vals[1]);
 }

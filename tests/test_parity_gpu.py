@@ -155,6 +155,18 @@ def test_scale_modifier(dgr, oracle):
     check_grads(h["grads"], oracle_backward(oracle, c, o, dL, scale_modifier=0.6), scale=64.0 * 64.0)
 
 
+def test_crowded_tiles_take_the_long_segment_path(dgr, oracle):
+    """More than 4096 instances in one tile: the per-tile depth sort leaves its in-register path."""
+    c = case(P=24000, W=32, H=32, D=0, seed=37, log_scale=(-5.0, -4.0), extent=(0.5, 0.5, 1.3))
+    o = oracle_forward(oracle, c)
+    per_tile = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert per_tile.max() > 4096 and per_tile.min() > 0
+    dL = torch.randn(3, 32, 32, generator=torch.Generator().manual_seed(12))
+    h = run_hip(dgr, c, dL_dpix=dL)
+    check_forward(o, h)
+    check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=32.0 * 32.0)
+
+
 def test_debug_mode_same_result(dgr, oracle):
     c = case(P=128, W=32, H=32, D=0, seed=23)
     o = oracle_forward(oracle, c)
