@@ -89,7 +89,7 @@ size_t ngs_required_image_bytes(int width, int height);
 /*
  * Introspection for parity tests: byte offsets (relative to the 256-byte
  * aligned base of each buffer) of the intermediate arrays, in this order:
- *  geometry[12]: xy_conicab(float4), conicc_opacity_rg(float4), blue(float),
+ *  geometry[10]: splat_record(16 floats per Gaussian: x, y, conic a, b, c, opacity, r, g, b, 7 unused),
  *                depth(float), tile_rect(uint2 packed lo|hi<<16), tiles_touched(u32),
  *                internal_radii(i32), clamped_bits(u8), block_sums(u32),
  *                block_offsets(u32), misc(u32[8]), grad_accumulator(float[16])

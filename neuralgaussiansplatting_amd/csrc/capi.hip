@@ -159,8 +159,8 @@ extern "C" int ngs_state_layout(int P, long long R, int W, int H, size_t* geomet
 {
     if (geometry) {
         const GeomLayout g = ngs_geom_layout((size_t)P);
-        const size_t v[12] = {g.g0, g.g1, g.g2, g.depth, g.rect, g.tiles, g.radii, g.clamped, g.block_sums,
-                              g.block_offs, g.misc, g.acc};
+        const size_t v[10] = {g.rec, g.depth, g.rect, g.tiles, g.radii, g.clamped, g.block_sums, g.block_offs,
+                              g.misc, g.acc};
         memcpy(geometry, v, sizeof v);
     }
     if (binning) {
@@ -208,9 +208,7 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     if (!ib) return fail("ngs_rasterize_forward", "image allocator returned NULL");
     ib = ngs_align_ptr(ib);
 
-    float4* g0 = (float4*)(gb + gl.g0);
-    float4* g1 = (float4*)(gb + gl.g1);
-    float* g2 = (float*)(gb + gl.g2);
+    float4* rec = (float4*)(gb + gl.rec);
     float* depth = (float*)(gb + gl.depth);
     uint2* rect = (uint2*)(gb + gl.rect);
     uint32_t* tiles = (uint32_t*)(gb + gl.tiles);
@@ -225,7 +223,7 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     NGS_HIP(hipMemsetAsync(misc, 0, 32, st));
     prof_begin(ps, ST_PREPROCESS, st);
     ngs_launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
-                              colors_precomp, cam, prefiltered, radii, g0, g1, g2, depth, rect, tiles, clamped,
+                              colors_precomp, cam, prefiltered, radii, rec, depth, rect, tiles, clamped,
                               block_sums, misc);
     prof_end(ps, ST_PREPROCESS, st);
     NGS_STAGE("preprocess");
@@ -277,7 +275,7 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
         NGS_STAGE("sort (depth)");
     }
     prof_begin(ps, ST_RENDER_FWD, st);
-    ngs_launch_render_fwd(st, cam, ranges, vals[0], g0, g1, g2, background, (float*)(ib + il.final_T),
+    ngs_launch_render_fwd(st, cam, ranges, vals[0], rec, background, (float*)(ib + il.final_T),
                           (uint32_t*)(ib + il.n_contrib), out_color);
     prof_end(ps, ST_RENDER_FWD, st);
     NGS_STAGE("render");
@@ -321,7 +319,7 @@ extern "C" int ngs_rasterize_backward(int P, int D, int M, int R, const float* b
     prof_end(ps, ST_BWD_ZERO, st);
     prof_begin(ps, ST_RENDER_BWD, st);
     ngs_launch_render_bwd(st, cam, (const uint2*)(ib + il.ranges), (const uint32_t*)(bb + bl.vals[0]),
-                          (const float4*)(gb + gl.g0), (const float4*)(gb + gl.g1), (const float*)(gb + gl.g2),
+                          (const float4*)(gb + gl.rec),
                           background, (const float*)(ib + il.final_T), (const uint32_t*)(ib + il.n_contrib), dL_dpix,
                           acc);
     prof_end(ps, ST_RENDER_BWD, st);

@@ -24,9 +24,9 @@ enum { ACC_DX = 0, ACC_DY, ACC_CON_A, ACC_CON_B, ACC_CON_C, ACC_OPAC, ACC_R, ACC
 // chunks (cuda_rasterizer/rasterizer_impl.cu:155-194,371-373).
 // ---------------------------------------------------------------------------
 struct GeomLayout {
-    size_t g0;         // float4[P]  {pixel x, pixel y, conic a, conic b}
-    size_t g1;         // float4[P]  {conic c, opacity, red, green}
-    size_t g2;         // float [P]  {blue}
+    size_t rec;        // float4[P][4] one 64-byte splat record per Gaussian, so that the compositing kernels'
+                       // gather touches ONE cache line per splat: [0] = {pixel x, pixel y, conic a, conic b},
+                       // [1] = {conic c, opacity, red, green}, [2] = {blue, -, -, -}, [3] unused
     size_t depth;      // float [P]  view-space z
     size_t rect;       // uint2 [P]  packed tile rectangle: x = min.x | max.x<<16, y = min.y | max.y<<16
     size_t tiles;      // u32   [P]  tiles touched
@@ -64,9 +64,7 @@ static inline GeomLayout ngs_geom_layout(size_t P)
 {
     GeomLayout l;
     size_t o = 0, nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
-    l.g0 = o; o = ngs_align_up(o + P * 16);
-    l.g1 = o; o = ngs_align_up(o + P * 16);
-    l.g2 = o; o = ngs_align_up(o + P * 4);
+    l.rec = o; o = ngs_align_up(o + P * 64);
     l.depth = o; o = ngs_align_up(o + P * 4);
     l.rect = o; o = ngs_align_up(o + P * 8);
     l.tiles = o; o = ngs_align_up(o + P * 4);
@@ -128,8 +126,8 @@ struct NgsCamera {
 // preprocess_fwd.hip
 void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* means, const float* scales, float mod,
                                const float* rots, const float* opac, const float* shs, const float* cov_pre,
-                               const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* g0,
-                               float4* g1, float* g2, float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
+                               const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* rec,
+                               float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
                                uint32_t* block_sums, uint32_t* misc);
 void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const float* view, uint8_t* present);
 // binning.hip
@@ -148,11 +146,11 @@ void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, uint64_
                               uint32_t* const vals[2]);
 // render_fwd.hip
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
-                           const float4* g0, const float4* g1, const float* g2, const float* bg, float* final_T,
+                           const float4* rec, const float* bg, float* final_T,
                            uint32_t* n_contrib, float* out_color);
 // render_bwd.hip
 void ngs_launch_render_bwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
-                           const float4* g0, const float4* g1, const float* g2, const float* bg, const float* final_T,
+                           const float4* rec, const float* bg, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, float* acc);
 // preprocess_bwd.hip
 void ngs_launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* means, const int* radii,

@@ -46,8 +46,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ rots, const float* __restrict__ opac, const float* __restrict__ shs,
     const float* __restrict__ cov_pre, const float* __restrict__ col_pre, const NgsCamera cam,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, int prefiltered,
-    int* __restrict__ radii, float4* __restrict__ g0, float4* __restrict__ g1, float* __restrict__ g2,
-    float* __restrict__ depth, uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint8_t* __restrict__ clamped,
+    int* __restrict__ radii, float4* __restrict__ rec, float* __restrict__ depth, uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint8_t* __restrict__ clamped,
     uint32_t* __restrict__ block_sums, uint32_t* __restrict__ misc)
 {
     __shared__ uint32_t wave_tot[NGS_GAUSS_BLOCK / 64];
@@ -103,9 +102,10 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
                         d = make_float3(d.x / len, d.y / len, d.z / len);
                         col = sh_to_rgb(D, shs + (size_t)3 * M * idx, d, cb);
                     }
-                    g0[idx] = make_float4(ix, iy, k.c * dinv, -k.b * dinv);
-                    g1[idx] = make_float4(k.a * dinv, opac[idx], col.x, col.y);
-                    g2[idx] = col.z;
+                    float4* r = rec + 4 * (size_t)idx;
+                    r[0] = make_float4(ix, iy, k.c * dinv, -k.b * dinv);
+                    r[1] = make_float4(k.a * dinv, opac[idx], col.x, col.y);
+                    r[2] = make_float4(col.z, 0.0f, 0.0f, 0.0f);
                     depth[idx] = pv.z;
                     rect[idx] = make_uint2(x0 | (x1 << 16), y0 | (y1 << 16));
                     clamped[idx] = (uint8_t)cb;
@@ -137,13 +137,13 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* _
 
 void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* means, const float* scales, float mod,
                                const float* rots, const float* opac, const float* shs, const float* cov_pre,
-                               const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* g0,
-                               float4* g1, float* g2, float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
+                               const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* rec,
+                               float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
                                uint32_t* block_sums, uint32_t* misc)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales, mod, rots,
-                       opac, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered, radii, g0, g1, g2, depth, rect, tiles, clamped,
+                       opac, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered, radii, rec, depth, rect, tiles, clamped,
                        block_sums, misc);
 }
 

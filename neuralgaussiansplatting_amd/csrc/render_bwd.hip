@@ -56,8 +56,7 @@ __device__ __forceinline__ float row_sum_lane15(float v)
 
 __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
-    const float4* __restrict__ g0, const float4* __restrict__ g1, const float* __restrict__ g2,
-    const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float4* __restrict__ splat_rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ acc)
 {
     // record k: [0] = {x, y, reach x, reach y}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
@@ -115,9 +114,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
         const int nb = min(NGS_TILE_PIX, first + 1);
         if (tid < nb) {
             const uint32_t id = plist[range.x + (uint32_t)(first - tid)];
-            const float4 a = g0[id];
-            const float4 b = g1[id];
-            const float c = g2[id];
+            const float4* gr = splat_rec + 4 * (size_t)id;  // one 64-byte line per splat
+            const float4 a = gr[0];
+            const float4 b = gr[1];
+            const float c = gr[2].x;
             const float2 h = splat_half_extent(a.z, a.w, b.x, b.y);
             s_rec[tid][0] = make_float4(a.x, a.y, h.x, h.y);
             s_rec[tid][1] = make_float4(a.z, a.w, b.x, b.y);
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
 }
 
 void ngs_launch_render_bwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
-                           const float4* g0, const float4* g1, const float* g2, const float* bg, const float* final_T,
+                           const float4* rec, const float* bg, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, float* acc)
 {
     hipLaunchKernelGGL(render_bwd_kernel, dim3(cam.grid_x * cam.grid_y), dim3(NGS_TILE_PIX), 0, s, cam.W, cam.H,
-                       cam.grid_x, ranges, plist, g0, g1, g2, bg, final_T, n_contrib, dL_dpix, acc);
+                       cam.grid_x, ranges, plist, rec, bg, final_T, n_contrib, dL_dpix, acc);
 }

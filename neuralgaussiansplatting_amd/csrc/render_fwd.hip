@@ -19,8 +19,7 @@
 
 __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
-    const float4* __restrict__ g0, const float4* __restrict__ g1, const float* __restrict__ g2,
-    const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+    const float4* __restrict__ rec_g, const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     float* __restrict__ out_color)
 {
     // per wave, record k: [0] = {x, y, -, -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, -}
@@ -46,10 +45,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     float4 na = make_float4(0, 0, 0, 0), nb = na;
     float nc = 0.0f;
     if (lane < n) {
-        const uint32_t id = plist[range.x + lane];
-        na = g0[id];
-        nb = g1[id];
-        nc = g2[id];
+        const float4* r = rec_g + 4 * (size_t)plist[range.x + lane];  // one 64-byte line per splat
+        na = r[0];
+        nb = r[1];
+        nc = r[2].x;
     }
     for (int base = 0; base < n; base += 64) {
         if (__ballot(!done) == 0ull) break;  // every pixel of the strip is saturated (or outside the image)
@@ -58,10 +57,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
         const bool have = base + lane < n;
         const int nxt = base + 64 + lane;
         if (nxt < n) {
-            const uint32_t id = plist[range.x + nxt];
-            na = g0[id];
-            nb = g1[id];
-            nc = g2[id];
+            const float4* r = rec_g + 4 * (size_t)plist[range.x + nxt];
+            na = r[0];
+            nb = r[1];
+            nc = r[2].x;
         }
         bool reach = false;
         if (have) {
@@ -107,9 +106,9 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
 }
 
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
-                           const float4* g0, const float4* g1, const float* g2, const float* bg, float* final_T,
+                           const float4* rec, const float* bg, float* final_T,
                            uint32_t* n_contrib, float* out_color)
 {
     hipLaunchKernelGGL(render_fwd_kernel, dim3(cam.grid_x * cam.grid_y), dim3(NGS_TILE_PIX), 0, s, cam.W, cam.H,
-                       cam.grid_x, ranges, plist, g0, g1, g2, bg, final_T, n_contrib, out_color);
+                       cam.grid_x, ranges, plist, rec, bg, final_T, n_contrib, out_color);
 }

@@ -18,13 +18,11 @@ def decode_state(_C, P, R, W, H, geom, binning, img):
     gl, bl, il = _C.state_layout(P, R, W, H)
     gx, gy = (W + 15) // 16, (H + 15) // 16
     T = gx * gy
-    a = _view(geom, gl["xy_conicab"], np.float32, 4 * P).reshape(P, 4)
-    b = _view(geom, gl["conicc_opacity_rg"], np.float32, 4 * P).reshape(P, 4)
-    c = _view(geom, gl["blue"], np.float32, P)
+    rec = _view(geom, gl["splat_record"], np.float32, 16 * P).reshape(P, 16)
     out = dict(
-        means2D=a[:, :2].copy(),
-        conic_opacity=np.stack([a[:, 2], a[:, 3], b[:, 0], b[:, 1]], axis=1),
-        rgb=np.stack([b[:, 2], b[:, 3], c], axis=1),
+        means2D=rec[:, 0:2].copy(),
+        conic_opacity=rec[:, 2:6].copy(),
+        rgb=rec[:, 6:9].copy(),
         depths=_view(geom, gl["depth"], np.float32, P),
         tile_rect=_view(geom, gl["tile_rect"], np.uint32, 2 * P).reshape(P, 2),
         tiles_touched=_view(geom, gl["tiles_touched"], np.uint32, P),

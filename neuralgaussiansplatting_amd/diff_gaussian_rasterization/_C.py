@@ -201,11 +201,11 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 def state_layout(P, R, W, H):
     """Byte offsets of the intermediates inside the three state buffers (parity tests)."""
-    g = (ctypes.c_size_t * 12)()
+    g = (ctypes.c_size_t * 10)()
     b = (ctypes.c_size_t * 2)()
     i = (ctypes.c_size_t * 3)()
     lib().ngs_state_layout(int(P), ctypes.c_longlong(int(R)), int(W), int(H), g, b, i)
-    names_g = ("xy_conicab", "conicc_opacity_rg", "blue", "depth", "tile_rect", "tiles_touched", "internal_radii",
+    names_g = ("splat_record", "depth", "tile_rect", "tiles_touched", "internal_radii",
                "clamped_bits", "block_sums", "block_offsets", "misc", "grad_accumulator")
     return (dict(zip(names_g, g)), dict(zip(("sorted_keys", "point_list"), b)),
             dict(zip(("final_T", "n_contrib", "ranges"), i)))
