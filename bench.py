@@ -9,8 +9,9 @@ per GPU on a synthetic scene, through the C ABI of libngs_rasterizer.so.
 A step = preprocess -> scan -> key emission -> radix sort -> tile ranges ->
 compositing forward, then compositing backward -> per-Gaussian backward, on
 inputs already resident in HBM; with N > 1 each rank renders its own view of
-the replicated scene and the step ends with one all-reduce (RCCL) of the
-per-Gaussian gradient bucket.  Rank 0 prints one JSON line.
+the replicated scene and the step ends with the exchange (RCCL) that leaves the
+sum over views of the per-Gaussian gradients on every rank (see
+neuralgaussiansplatting_amd/view_parallel.py).  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -81,6 +82,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c4", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--exchange", default="factored", choices=("factored", "dense"),
+                    help="gradient exchange at N > 1: all-gather of masked colour gradients + all-reduce of the other "
+                         "11 floats per Gaussian (default), or one dense all-reduce of all 59")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo lets several ranks share one GPU to rehearse the N > 1 path on a one-GPU box")
+    ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
     args = ap.parse_args()
@@ -93,10 +100,15 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the rasterizer has no CPU path)")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     P, W, H, D, M, _, _ = synthetic.CONFIGS[args.config]
     scene_cpu, W, H = synthetic.make_config(args.config, seed=1234)  # same seed everywhere: replicated parameters
@@ -106,11 +118,16 @@ def main():
     bg = torch.zeros(3, device=dev)
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     dL = (torch.randn(3, H, W, generator=gen) / float(W * H)).to(dev)
-    bucket = view_parallel.GradientBucket(P, M, dev)
+    if world > 1 and args.exchange == "factored":
+        bucket = view_parallel.FactoredGradientExchange(P, M, dev)
+        exchanged_floats = bucket.row + bucket.reduced.numel()
+    else:
+        bucket = view_parallel.GradientBucket(P, M, dev)
+        exchanged_floats = bucket.flat.numel()
 
     def step():
         out = view_parallel.forward_backward(scene, cam, bg, lambda color: dL, bucket, tanx, tany)
-        bucket.all_reduce()
+        bucket.reduce(scene, cam, out[2])
         return out
 
     def fence():
@@ -119,8 +136,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(max(args.warmup, 1)):
+    def note(msg):
+        if args.verbose:
+            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+
+    note("scene and view resident")
+    for i in range(max(args.warmup, 1)):
         color, radii, aux = step()
+        torch.cuda.synchronize(dev)
+        note("warm-up step %d done" % i)
     # workload statistics of this rank's view (cost is linear in them)
     R = aux["num_rendered"]
     vis = float((radii > 0).float().mean())
@@ -132,10 +156,11 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    note("timed steps done")
     stages = _C.profile_read(reset=True)
     _C.profile_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -183,8 +208,8 @@ def main():
             "iters_per_s": round(world * args.steps / elapsed, 2),
             "config": {"workload": "%s: %d Gaussians, %dx%d, SH degree %d (M=%d), one orbit view per GPU, "
                                    "fwd+bwd%s" % (args.config, P, W, H, D, M,
-                                                  " + all-reduce of %d floats" % bucket.flat.numel() if world > 1
-                                                  else ""),
+                                                  " + %s gradient exchange of %d floats per rank"
+                                                  % (args.exchange, exchanged_floats) if world > 1 else ""),
                        "gaussians": P, "width": W, "height": H, "sh_degree": D, "instances_R": int(R),
                        "visible_fraction": round(vis, 4), "instances_per_tile_mean": round(float(per_tile.mean()), 1),
                        "instances_per_tile_max": int(per_tile.max()),

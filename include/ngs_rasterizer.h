@@ -61,7 +61,8 @@ int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_a
  * geom_buffer / binning_buffer / image_buffer are the buffers the forward call
  * filled (or copies of them at addresses with the same residue modulo 256;
  * they are re-carved from P, R and the image size).  Every output element is WRITTEN (zeros for culled Gaussians), so
- * the caller need not zero-fill; dL_dconic ([P][2][2]) may be NULL.
+ * the caller need not zero-fill; dL_dconic ([P][2][2]) may be NULL, and so may dL_dsh (the SH coefficient gradient
+ * is then not produced; its share of dL_dmean3D still is -- see ngs_sh_gradient_from_views).
  * Shapes: dL_dpix [3][H][W]; dL_dmean2D [P][3]; dL_dopacity [P]; dL_dcolor
  * [P][3]; dL_dmean3D [P][3]; dL_dcov3D [P][6]; dL_dsh [P][M][3]; dL_dscale
  * [P][3]; dL_drot [P][4].
@@ -85,6 +86,25 @@ int ngs_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 size_t ngs_required_geometry_bytes(int P);
 size_t ngs_required_binning_bytes(long long R);
 size_t ngs_required_image_bytes(int width, int height);
+
+/*
+ * View-factored SH gradient, for callers that sum gradients over several views (view-sharded data parallelism).
+ * No counterpart in the reference, which renders one view per step on one GPU (train.py:76-78).
+ * Per view, dL_dsh[k] = basis_k(view direction) * masked dL_dcolor (backward.cu:42-137), so instead of exchanging
+ * 3*M floats per Gaussian and view, ranks exchange the masked colour gradient (3 floats) and every rank rebuilds
+ *     dL_dsh[i][k][c] = sum over v of basis_k(means3D[i] - campos[v]) * dL_dcolor_views[v][i][c]
+ * adding the views in index order (identical bits on every rank; equal to the per-view dL_dsh for V == 1).
+ *
+ * ngs_masked_color_gradient: out[i][c] = dL_dcolor[i][c], or 0 where channel c of Gaussian i was clamped in the
+ * forward pass whose geometry buffer is given (out may alias dL_dcolor).
+ * ngs_sh_gradient_from_views: campos holds V positions campos_stride floats apart, dL_dcolor_views holds V
+ * arrays [P][3] view_stride floats apart (so both may point into one gathered buffer); dL_dsh is [P][M][3] and
+ * every element is written.
+ */
+int ngs_masked_color_gradient(int P, const char* geom_buffer, const float* dL_dcolor, float* out, void* stream);
+int ngs_sh_gradient_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
+                               long long campos_stride, const float* dL_dcolor_views, long long view_stride,
+                               float* dL_dsh, void* stream);
 
 /*
  * Introspection for parity tests: byte offsets (relative to the 256-byte

@@ -301,7 +301,7 @@ extern "C" int ngs_rasterize_backward(int P, int D, int M, int R, const float* b
     if (!means3D || !viewmatrix || !projmatrix || !background || !dL_dpix || !dL_dmean2D || !dL_dopacity ||
         !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
         return fail("ngs_rasterize_backward", "missing required pointer");
-    if (shs && (!dL_dsh || !campos)) return fail("ngs_rasterize_backward", "shs given without dL_dsh / campos");
+    if (shs && !campos) return fail("ngs_rasterize_backward", "shs given without campos");
     if (!cov3D_precomp && (!scales || !rotations)) return fail("ngs_rasterize_backward", "need scales+rotations or cov3D_precomp");
     const NgsCamera cam = make_camera(width, height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos);
     const GeomLayout gl = ngs_geom_layout((size_t)P);
@@ -333,6 +333,41 @@ extern "C" int ngs_rasterize_backward(int P, int D, int M, int R, const float* b
                               dL_drot);
     prof_end(ps, ST_PREPROCESS_BWD, st);
     NGS_STAGE("preprocess backward");
+    return 0;
+}
+
+extern "C" int ngs_masked_color_gradient(int P, const char* geom_buffer, const float* dL_dcolor, float* out,
+                                         void* stream)
+{
+    g_err[0] = 0;
+    if (P < 0) return fail("ngs_masked_color_gradient", "bad size");
+    if (P == 0) return 0;
+    if (!geom_buffer || !dL_dcolor || !out) return fail("ngs_masked_color_gradient", "missing required pointer");
+    const GeomLayout gl = ngs_geom_layout((size_t)P);
+    const char* gb = ngs_align_ptr((char*)geom_buffer);
+    ngs_launch_masked_color((hipStream_t)stream, P, (const uint8_t*)(gb + gl.clamped), dL_dcolor, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("stage masked colour gradient", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int ngs_sh_gradient_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
+                                          long long campos_stride, const float* dL_dcolor_views,
+                                          long long view_stride, float* dL_dsh, void* stream)
+{
+    g_err[0] = 0;
+    if (P < 0 || V < 1) return fail("ngs_sh_gradient_from_views", "bad sizes");
+    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M)
+        return fail("ngs_sh_gradient_from_views", "SH degree does not fit the coefficient count");
+    if (P == 0) return 0;
+    if (!means3D || !campos || !dL_dcolor_views || !dL_dsh)
+        return fail("ngs_sh_gradient_from_views", "missing required pointer");
+    if (campos_stride < 3 || view_stride < 3LL * P)
+        return fail("ngs_sh_gradient_from_views", "view strides shorter than one view's data");
+    ngs_launch_sh_from_views((hipStream_t)stream, P, D, M, V, means3D, campos, campos_stride, dL_dcolor_views,
+                             view_stride, dL_dsh);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("stage SH gradient from views", hipGetErrorString(e));
     return 0;
 }
 

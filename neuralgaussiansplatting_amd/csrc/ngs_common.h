@@ -159,6 +159,12 @@ void ngs_launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* 
                                float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                                float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
 
+// sh_views.hip: per-Gaussian colour gradient with the clamp mask applied, and the SH coefficient gradient summed
+// over V views from those masked colour gradients.
+void ngs_launch_masked_color(hipStream_t s, int P, const uint8_t* clamped, const float* dL_dcolor, float* out);
+void ngs_launch_sh_from_views(hipStream_t s, int P, int D, int M, int V, const float* means, const float* campos,
+                              long long campos_stride, const float* colors, long long colors_stride, float* dL_dsh);
+
 #ifdef __HIPCC__
 // ---------------------------------------------------------------------------
 // Device math shared by preprocess forward and backward.  Matrices are stored
@@ -290,6 +296,36 @@ __device__ __forceinline__ float3 f3_scale(float s, float3 v) { return make_floa
 __device__ __forceinline__ float3 f3_add(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ float3 f3_sub(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ float f3_dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// d(colour)/d(sh[k]) for a unit view direction (x, y, z): the SH basis value of coefficient k
+// (cuda_rasterizer/backward.cu:49-137).  Sets w[0 .. (deg+1)^2).  Shared by the per-view SH backward and by the
+// view-factored SH gradient so both form the same products.
+__device__ __forceinline__ void sh_basis_weights(int deg, float x, float y, float z, float* w)
+{
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    w[0] = NGS_SH_C0;
+    if (deg > 0) {
+        w[1] = -NGS_SH_C1 * y;
+        w[2] = NGS_SH_C1 * z;
+        w[3] = -NGS_SH_C1 * x;
+        if (deg > 1) {
+            w[4] = NGS_SH_C2_0 * xy;
+            w[5] = NGS_SH_C2_1 * yz;
+            w[6] = NGS_SH_C2_2 * (2.f * zz - xx - yy);
+            w[7] = NGS_SH_C2_3 * xz;
+            w[8] = NGS_SH_C2_4 * (xx - yy);
+            if (deg > 2) {
+                w[9] = NGS_SH_C3_0 * y * (3.f * xx - yy);
+                w[10] = NGS_SH_C3_1 * xy * z;
+                w[11] = NGS_SH_C3_2 * y * (4.f * zz - xx - yy);
+                w[12] = NGS_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                w[13] = NGS_SH_C3_4 * x * (4.f * zz - xx - yy);
+                w[14] = NGS_SH_C3_5 * z * (xx - yy);
+                w[15] = NGS_SH_C3_6 * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
 
 // Sum over the 64 lanes of a wave; the total is valid in lane 63 only.
 // Row-wise inclusive scan by DPP row shifts, then two row broadcasts.

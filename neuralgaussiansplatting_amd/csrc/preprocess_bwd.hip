@@ -21,9 +21,9 @@
 #define SH_ROW_LDS 52  // padded LDS row stride
 
 // backward.cu:20-139.  Writes dL_dsh[0..M) for this Gaussian (zeros above the
-// active degree) and returns the gradient wrt the mean through the view
-// direction.  `shs` and `dsh_out` may be the SAME row (LDS staging): every read
-// of a coefficient happens before the first write.
+// active degree) unless `dsh_out` is NULL, and returns the gradient wrt the mean
+// through the view direction.  `shs` and `dsh_out` may be the SAME row (LDS
+// staging): every read of a coefficient happens before the first write.
 __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const float* __restrict__ campos,
                                               const float* shs, uint32_t clamp_bits, float3 dRGB, float* dsh_out)
 {
@@ -97,34 +97,16 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const 
     // every coefficient has been read; a compiler-level fence keeps the writes below after the reads above
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- phase 2 (writes): gradient of each coefficient ----
-    g[0] = f3_scale(NGS_SH_C0, dRGB);
-    int written = 1;
-    if (deg > 0) {
-        g[1] = f3_scale(-NGS_SH_C1 * y, dRGB);
-        g[2] = f3_scale(NGS_SH_C1 * z, dRGB);
-        g[3] = f3_scale(-NGS_SH_C1 * x, dRGB);
-        written = 4;
-        if (deg > 1) {
-            g[4] = f3_scale(NGS_SH_C2_0 * xy, dRGB);
-            g[5] = f3_scale(NGS_SH_C2_1 * yz, dRGB);
-            g[6] = f3_scale(NGS_SH_C2_2 * (2.f * zz - xx - yy), dRGB);
-            g[7] = f3_scale(NGS_SH_C2_3 * xz, dRGB);
-            g[8] = f3_scale(NGS_SH_C2_4 * (xx - yy), dRGB);
-            written = 9;
-            if (deg > 2) {
-                g[9] = f3_scale(NGS_SH_C3_0 * y * (3.f * xx - yy), dRGB);
-                g[10] = f3_scale(NGS_SH_C3_1 * xy * z, dRGB);
-                g[11] = f3_scale(NGS_SH_C3_2 * y * (4.f * zz - xx - yy), dRGB);
-                g[12] = f3_scale(NGS_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy), dRGB);
-                g[13] = f3_scale(NGS_SH_C3_4 * x * (4.f * zz - xx - yy), dRGB);
-                g[14] = f3_scale(NGS_SH_C3_5 * z * (xx - yy), dRGB);
-                g[15] = f3_scale(NGS_SH_C3_6 * x * (xx - 3.f * yy), dRGB);
-                written = 16;
-            }
-        }
+    // ---- phase 2 (writes): gradient of each coefficient; skipped when the caller does not want it ----
+    if (g) {
+        float w[16];
+        sh_basis_weights(deg, x, y, z, w);
+        const int coeffs = (deg + 1) * (deg + 1);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < coeffs) g[k] = f3_scale(w[k], dRGB);
+        for (int k = coeffs; k < M; k++) g[k] = make_float3(0.0f, 0.0f, 0.0f);
     }
-    for (int k = written; k < M; k++) g[k] = make_float3(0.0f, 0.0f, 0.0f);
     return dmean;
 }
 
@@ -173,7 +155,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         dL_dmean3D[3 * i] = 0.0f; dL_dmean3D[3 * i + 1] = 0.0f; dL_dmean3D[3 * i + 2] = 0.0f;
 #pragma unroll
         for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.0f;
-        if (!SH_LDS)
+        if (!SH_LDS && dL_dsh)
             for (int k = 0; k < 3 * M; k++) dL_dsh[(size_t)3 * M * i + k] = 0.0f;
         dL_dscale[3 * i] = 0.0f; dL_dscale[3 * i + 1] = 0.0f; dL_dscale[3 * i + 2] = 0.0f;
         ((float4*)dL_drot)[i] = make_float4(0, 0, 0, 0);
@@ -272,7 +254,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         // ---- SH backward ----
         if (shs) {
             const float* sh_in = SH_LDS ? my_row : shs + (size_t)3 * M * i;
-            float* sh_out = SH_LDS ? my_row : dL_dsh + (size_t)3 * M * i;
+            float* sh_out = !dL_dsh ? nullptr : SH_LDS ? my_row : dL_dsh + (size_t)3 * M * i;
             const float3 ds = sh_backward(D, M, make_float3(mx, my, mz), campos, sh_in, clamped[i], g_col, sh_out);
             dmean.x += ds.x; dmean.y += ds.y; dmean.z += ds.z;
         }
@@ -313,7 +295,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         }
     }
 
-    if (SH_LDS) {
+    if (SH_LDS && dL_dsh) {
         __syncthreads();
         // the wave's 64 gradient rows leave as 12 fully coalesced 1-KiB stores; culled Gaussians get zeros
 #pragma unroll

@@ -1,0 +1,103 @@
+// View-factored SH gradient for view-sharded data parallelism.
+//
+// For one view the gradient of SH coefficient k of a Gaussian is
+//     dL_dsh[k] = basis_k(direction from that view's camera) * dL_dRGB        (backward.cu:49-137)
+// with dL_dRGB the colour gradient after the clamp mask (backward.cu:42-47).
+// Summed over V views this does not have to travel as 3*M floats per Gaussian
+// and view: every rank can rebuild the sum from the V masked colour gradients
+// (3 floats per Gaussian and view) and the V camera positions, which is what
+// sh_from_views_kernel does.  All ranks add the views in the same order, so
+// they end up with bit-identical sums.  The products are formed by the same
+// expression as the per-view backward (sh_basis_weights), so for V == 1 the
+// result equals the per-view dL_dsh bit for bit.
+#include "ngs_common.h"
+
+#define SH_ROW 48      // floats per Gaussian when M == 16
+#define SH_ROW_LDS 52  // padded LDS row stride (conflict-free 128-bit accesses)
+
+// out[i] = dL_dcolor[i] with the channels that were clamped in the forward pass zeroed.
+__global__ __launch_bounds__(NGS_GAUSS_BLOCK) void masked_color_kernel(int P, const uint8_t* __restrict__ clamped,
+                                                                      const float* __restrict__ dL_dcolor,
+                                                                      float* __restrict__ out)
+{
+    const int idx = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
+    if (idx >= P) return;
+    const size_t i = (size_t)idx;
+    const uint32_t bits = clamped[i];
+    out[3 * i] = dL_dcolor[3 * i] * ((bits & 1u) ? 0.0f : 1.0f);
+    out[3 * i + 1] = dL_dcolor[3 * i + 1] * ((bits & 2u) ? 0.0f : 1.0f);
+    out[3 * i + 2] = dL_dcolor[3 * i + 2] * ((bits & 4u) ? 0.0f : 1.0f);
+}
+
+// One lane per Gaussian.  LDS: M == 16, the 64 rows of a wave (12 KiB contiguous) leave through LDS as coalesced
+// 16-byte stores instead of 64 scattered 192-byte rows.
+template <bool LDS>
+__global__ __launch_bounds__(NGS_GAUSS_BLOCK) void sh_from_views_kernel(
+    int P, int D, int M, int V, const float* __restrict__ means, const float* __restrict__ campos,
+    long long campos_stride, const float* __restrict__ colors, long long colors_stride, float* __restrict__ dL_dsh)
+{
+    __shared__ float s_sh[LDS ? NGS_GAUSS_BLOCK * SH_ROW_LDS : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * NGS_GAUSS_BLOCK + tid;
+    const size_t i = (size_t)idx;
+    const int coeffs = (D + 1) * (D + 1);
+    float3 acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] = make_float3(0.0f, 0.0f, 0.0f);
+    if (idx < P) {
+        const float3 pos = make_float3(means[3 * i], means[3 * i + 1], means[3 * i + 2]);
+        for (int v = 0; v < V; v++) {
+            const float* g_ptr = colors + (size_t)v * colors_stride + 3 * i;
+            const float3 g = make_float3(g_ptr[0], g_ptr[1], g_ptr[2]);
+            if (g.x == 0.0f && g.y == 0.0f && g.z == 0.0f) continue;  // culled or unseen in this view: adds zeros
+            const float* cp = campos + (size_t)v * campos_stride;
+            // view direction exactly as in the forward and backward SH code (forward.cu:27-29)
+            const float3 d0 = make_float3(pos.x - cp[0], pos.y - cp[1], pos.z - cp[2]);
+            const float len = sqrtf(f3_dot(d0, d0));
+            float w[16];
+            sh_basis_weights(D, d0.x / len, d0.y / len, d0.z / len, w);
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < coeffs) acc[k] = f3_add(acc[k], f3_scale(w[k], g));
+        }
+    }
+    if (LDS) {
+        float* const wrows = s_sh + wave * 64 * SH_ROW_LDS;
+        float3* const row = (float3*)(wrows + lane * SH_ROW_LDS);
+#pragma unroll
+        for (int k = 0; k < 16; k++) row[k] = acc[k];
+        __syncthreads();
+        const int wave_first = blockIdx.x * NGS_GAUSS_BLOCK + wave * 64;
+#pragma unroll
+        for (int t = 0; t < SH_ROW * 64 / 4 / 64; t++) {
+            const int f = t * 64 + lane, g = f / (SH_ROW / 4), c = f - g * (SH_ROW / 4);
+            if (wave_first + g < P)
+                ((float4*)(dL_dsh + (size_t)(wave_first + g) * SH_ROW))[c] =
+                    *(const float4*)(wrows + g * SH_ROW_LDS + c * 4);
+        }
+    } else if (idx < P) {
+        float3* out = (float3*)(dL_dsh + (size_t)3 * M * i);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < coeffs && k < M) out[k] = acc[k];
+        for (int k = coeffs; k < M; k++) out[k] = make_float3(0.0f, 0.0f, 0.0f);
+    }
+}
+
+void ngs_launch_masked_color(hipStream_t s, int P, const uint8_t* clamped, const float* dL_dcolor, float* out)
+{
+    const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    hipLaunchKernelGGL(masked_color_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, clamped, dL_dcolor, out);
+}
+
+void ngs_launch_sh_from_views(hipStream_t s, int P, int D, int M, int V, const float* means, const float* campos,
+                              long long campos_stride, const float* colors, long long colors_stride, float* dL_dsh)
+{
+    const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    if (M == 16 && (uintptr_t)dL_dsh % 16 == 0)
+        hipLaunchKernelGGL(sh_from_views_kernel<true>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, V, means, campos,
+                           campos_stride, colors, colors_stride, dL_dsh);
+    else
+        hipLaunchKernelGGL(sh_from_views_kernel<false>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, V, means,
+                           campos, campos_stride, colors, colors_stride, dL_dsh);
+}

@@ -36,6 +36,8 @@ def lib():
         L.ngs_rasterize_backward.restype = ctypes.c_int
         L.ngs_mark_visible.restype = ctypes.c_int
         L.ngs_state_layout.restype = ctypes.c_int
+        L.ngs_masked_color_gradient.restype = ctypes.c_int
+        L.ngs_sh_gradient_from_views.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -119,11 +121,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 return_conic=False, out=None):
+                                 return_conic=False, out=None, skip_sh=False):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     (rasterize_points.cu:195); with ``return_conic`` a ninth element dL_dconic [P,2,2] is appended.
     ``out`` may map any of those names to a preallocated contiguous float32 tensor of the right size (for
-    instance a slice of one flat gradient bucket that is all-reduced afterwards); the rest are allocated here."""
+    instance a slice of one flat gradient bucket that is all-reduced afterwards); the rest are allocated here.
+    With ``skip_sh`` the SH coefficient gradient is not produced (None in its place): a view-parallel caller
+    rebuilds it for all views at once with ``sh_gradient_from_views``."""
     _require_gpu(means3D)
     dev = means3D.device
     P = means3D.size(0)
@@ -152,7 +156,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dconic = mk("dL_dconic", (P, 2, 2)) if return_conic else None
     dL_dopacity = mk("dL_dopacity", (P, 1))
     dL_dcov3D = mk("dL_dcov3D", (P, 6))
-    dL_dsh = mk("dL_dsh", (P, M, 3))
+    dL_dsh = None if skip_sh else mk("dL_dsh", (P, M, 3))
     dL_dscales = mk("dL_dscales", (P, 3))
     dL_drotations = mk("dL_drotations", (P, 4))
     if P != 0:
@@ -167,6 +171,51 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 int(bool(debug)), _stream(dev)))
     res = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     return res + (dL_dconic,) if return_conic else res
+
+
+def masked_color_gradient(geomBuffer, dL_dcolors, out=None):
+    """dL_dcolors [P,3] with the channels clamped in the forward pass (flags in ``geomBuffer``) zeroed: the
+    colour gradient that actually reaches the SH coefficients (backward.cu:42-47)."""
+    _require_gpu(dL_dcolors)
+    dev = dL_dcolors.device
+    P = dL_dcolors.size(0)
+    dL_dcolors = _f32(dL_dcolors, dev)
+    if out is None:
+        out = torch.empty_like(dL_dcolors)
+    elif out.numel() != 3 * P or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous():
+        raise RuntimeError("out must be a contiguous float32 tensor with %d elements on %s" % (3 * P, dev))
+    if P != 0:
+        with torch.cuda.device(dev):
+            _check(lib().ngs_masked_color_gradient(P, _ptr(geomBuffer), _ptr(dL_dcolors), _ptr(out), _stream(dev)))
+    return out.view(P, 3)
+
+
+def sh_gradient_from_views(means3D, campos, dL_dcolor_views, degree, M, out=None):
+    """Sum over views of the SH coefficient gradient, rebuilt from per-view masked colour gradients.
+
+    ``campos`` [V,3] and ``dL_dcolor_views`` [V,P,3] may be strided along the view axis (rows of one gathered
+    buffer) but must be contiguous within a view.  -> dL_dsh [P,M,3]."""
+    _require_gpu(means3D)
+    dev = means3D.device
+    P, V = means3D.size(0), dL_dcolor_views.size(0)
+    means3D = _f32(means3D, dev)
+    for t, inner in ((campos, 3), (dL_dcolor_views, 3 * P)):
+        if t.device != dev or t.dtype != torch.float32:
+            raise RuntimeError("view data must be float32 on %s" % dev)
+        if t.size(0) != V or t[0].numel() != inner or not t[0].is_contiguous():
+            raise RuntimeError("view data must hold one contiguous block of %d floats per view" % inner)
+    if out is None:
+        out = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
+    elif out.numel() != 3 * M * P or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous():
+        raise RuntimeError("out must be a contiguous float32 tensor with %d elements on %s" % (3 * M * P, dev))
+    if P != 0:
+        cs = campos.stride(0) if V > 1 else 3
+        vs = dL_dcolor_views.stride(0) if V > 1 else 3 * P
+        with torch.cuda.device(dev):
+            _check(lib().ngs_sh_gradient_from_views(
+                P, int(degree), int(M), V, _ptr(means3D), _ptr(campos), ctypes.c_longlong(cs),
+                _ptr(dL_dcolor_views), ctypes.c_longlong(vs), _ptr(out), _stream(dev)))
+    return out.view(P, M, 3)
 
 
 def profile_enable(on=True):

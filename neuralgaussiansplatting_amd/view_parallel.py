@@ -7,10 +7,22 @@ camera view forward and backward, and the per-Gaussian gradients of all ranks
 are summed by ONE all-reduce per step (RCCL over xGMI with the ``nccl``
 backend; ``gloo`` works on CPU tensors for tests).
 
-To make that a single collective without a packing copy, the backward pass
-writes its five parameter gradients straight into slices of one flat bucket:
+Two forms of the exchange are provided; both leave every rank with the sum over
+all views of the five parameter gradients.
+
+``GradientBucket`` (dense): the backward pass writes its five parameter
+gradients straight into slices of one flat bucket, which is all-reduced:
 
     [ dL_dmeans3D 3P | dL_dsh 3MP | dL_dopacity P | dL_dscales 3P | dL_drotations 4P ]
+
+``FactoredGradientExchange``: 3M of those 3M+11 floats per Gaussian are the SH
+coefficient gradient, which for one view is just basis(view direction) x (the
+clamp-masked colour gradient, 3 floats).  So each rank contributes its masked
+colour gradient and camera position to an all-gather (3 floats per Gaussian and
+view instead of 3M), the other 11 floats go through a small all-reduce, and every
+rank rebuilds the summed SH gradient locally, adding the views in rank order.
+On 8 GPUs at M = 16 that moves about 2.6x fewer bytes per GPU than the dense
+all-reduce, and all ranks hold bit-identical SH gradients.
 """
 import torch
 import torch.distributed as dist
@@ -18,6 +30,29 @@ import torch.distributed as dist
 from .diff_gaussian_rasterization import _C
 
 BUCKET_FIELDS = ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations")
+
+
+def _all_reduce_sum(t, group=None):
+    """Sum ``t`` over the ranks in place.  RCCL works on the device tensor; with gloo (CPU tests, or several
+    ranks rehearsing on one GPU) a device tensor is staged through host memory."""
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather_rows(rows, local, group=None):
+    """rows[r] <- rank r's ``local`` (rows is [world, n], contiguous)."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(rows.view(-1), local, group=group)
+    elif rows.is_cuda:
+        h = torch.empty(rows.shape, dtype=rows.dtype)
+        dist.all_gather(list(h.unbind(0)), local.cpu(), group=group)
+        rows.copy_(h)
+    else:
+        dist.all_gather(list(rows.unbind(0)), local, group=group)
 
 
 def bucket_layout(P, M):
@@ -32,6 +67,7 @@ def bucket_layout(P, M):
 
 class GradientBucket:
     """One flat float32 buffer holding every parameter gradient of a step."""
+    skip_sh = False  # the backward pass produces dL_dsh itself
 
     def __init__(self, P, M, device):
         self.P, self.M = P, M
@@ -49,10 +85,72 @@ class GradientBucket:
         """Sum (or mean) the bucket over all ranks: the step's only collective."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return None
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-        if average and not async_op:
+        if async_op:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        _all_reduce_sum(self.flat, group)
+        if average:
             self.flat.div_(dist.get_world_size(group))
-        return work
+        return None
+
+
+    def reduce(self, scene=None, cam=None, aux=None, group=None):
+        """Uniform entry point of both exchange forms (the dense one needs none of the arguments)."""
+        return self.all_reduce(group=group)
+
+
+REDUCED_FIELDS = ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")
+
+
+class FactoredGradientExchange:
+    """Gradient exchange with the SH part factored into (masked colour gradient, camera position) per view.
+
+    ``views`` are the backward pass's output slices (``skip_sh`` tells it not to produce dL_dsh);
+    ``reduce(scene, cam, aux)`` runs the exchange; afterwards ``shaped()`` holds the all-view sums."""
+    skip_sh = True
+
+    def __init__(self, P, M, device, world_size=None, group=None):
+        self.P, self.M, self.group = P, M, group
+        if world_size is None:
+            world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = world_size
+        sizes = (3 * P, P, 3 * P, 4 * P)
+        self.reduced = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        self.views, off = {}, 0
+        for name, n in zip(REDUCED_FIELDS, sizes):
+            self.views[name] = self.reduced[off:off + n]
+            off += n
+        self.row = 3 * P + 4  # one view's contribution: masked colour gradient [P,3], camera position, one pad
+        self.local = torch.zeros(self.row, dtype=torch.float32, device=device)
+        self.gathered = torch.zeros((self.world, self.row), dtype=torch.float32, device=device)
+        self.dL_dsh = torch.empty((P, M, 3), dtype=torch.float32, device=device)
+
+    def shaped(self):
+        P = self.P
+        shapes = dict(dL_dmeans3D=(P, 3), dL_dopacity=(P, 1), dL_dscales=(P, 3), dL_drotations=(P, 4))
+        out = {k: v.view(shapes[k]) for k, v in self.views.items()}
+        out["dL_dsh"] = self.dL_dsh
+        return out
+
+    def bytes_sent_per_rank(self):
+        """Payload each rank contributes to the two collectives (float32 bytes)."""
+        return 4 * (self.row + self.reduced.numel())
+
+    def reduce(self, scene, cam, aux, group=None):
+        """``aux`` is what ``forward_backward`` returned for this rank's view (it carries the geometry buffer with
+        the clamp flags and the raw colour gradient)."""
+        group = group if group is not None else self.group
+        P = self.P
+        _C.masked_color_gradient(aux["geom"], aux["dL_dcolors"], out=self.local[:3 * P])
+        self.local[3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
+        if self.world > 1:
+            _all_gather_rows(self.gathered, self.local, group)
+            _all_reduce_sum(self.reduced, group)
+            gathered = self.gathered
+        else:
+            gathered = self.local.view(1, self.row)
+        _C.sh_gradient_from_views(scene.means3D, gathered[:, 3 * P:3 * P + 3], gathered[:, :3 * P], scene.sh_degree,
+                                  self.M, out=self.dL_dsh)
+        return None
 
 
 def shard_views(num_views, rank, world_size):
@@ -63,7 +161,8 @@ def shard_views(num_views, rank, world_size):
 def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale_modifier=1.0, debug=False):
     """One pass of the hot path for one view on this rank's GPU: rasterize,
     obtain dL/dpixel from ``dL_dpix_fn(color)``, run the backward pass with the
-    parameter gradients landing in ``bucket``.  Returns (color, radii, aux grads)."""
+    parameter gradients landing in ``bucket`` (either exchange form; ``bucket.reduce(scene, cam, aux)`` then
+    sums them over the ranks).  Returns (color, radii, aux)."""
     e = torch.empty(0)
     H, W = int(cam.image_height), int(cam.image_width)
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(
@@ -74,5 +173,5 @@ def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale
     res = _C.rasterize_gaussians_backward(
         bg, scene.means3D, radii, e, scene.scales, scene.rotations, scale_modifier, e, cam.world_view_transform,
         cam.full_proj_transform, tanfovx, tanfovy, dL_dpix, scene.shs, scene.sh_degree, cam.camera_center, geom, R,
-        binning, img, debug, out=bucket.views)
-    return color, radii, dict(num_rendered=R, dL_dmeans2D=res[0], dL_dcolors=res[1], dL_dcov3D=res[4])
+        binning, img, debug, out=bucket.views, skip_sh=bucket.skip_sh)
+    return color, radii, dict(num_rendered=R, dL_dmeans2D=res[0], dL_dcolors=res[1], dL_dcov3D=res[4], geom=geom)

@@ -322,3 +322,61 @@ def test_render_entry_point_autograd(dgr, oracle):
     np.testing.assert_allclose(a.cpu().numpy(), o["out_color"], atol=1e-5, rtol=0)
     np.testing.assert_allclose(b.cpu().numpy(), o["out_color"], atol=3e-4, rtol=0)
     assert float(ov.max()) <= 0.25 + 1e-6
+
+
+@pytest.mark.parametrize("D,M,P", [(3, 16, 3000), (2, 9, 700), (1, 16, 260), (0, 1, 200)])
+def test_view_factored_sh_gradient_equals_sum_of_per_view_gradients(D, M, P, dgr, oracle):
+    """The multi-view exchange rebuilds sum_v dL_dsh(v) from masked colour gradients: it must equal the per-view
+    SH gradients added in view order bit for bit, and the clamp mask must be the checker's."""
+    from neuralgaussiansplatting_amd import view_parallel
+    from neuralgaussiansplatting_amd.cameras import make_camera
+    from neuralgaussiansplatting_amd import synthetic
+    dev = torch.device("cuda:0")
+    eyes = [(0.7, 0.5, -4.0), (-2.5, 0.3, -3.0), (0.2, -0.4, -1.2)]
+    c = case(P=P, W=80, H=64, D=D, M=M, seed=17)
+    # strong higher bands so that some channels clamp in some views
+    c["scene"].shs[:, 1:] *= 6.0
+    scene = c["scene"].to(dev)
+    bg = c["bg"].to(dev)
+    dense_sum, masked_rows, campos, other = None, [], [], None
+    for v, eye in enumerate(eyes):
+        cam_cpu = make_camera(c["W"], c["H"], synthetic.FOVX, eye)
+        cam = make_camera(c["W"], c["H"], synthetic.FOVX, eye, device=dev)
+        dL = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(50 + v)).to(dev)
+        dense = view_parallel.GradientBucket(P, M, dev)
+        _, radii, aux = view_parallel.forward_backward(scene, cam, bg, lambda color: dL, dense, c["tanfovx"],
+                                                       c["tanfovy"])
+        torch.cuda.synchronize()
+        d = dense.shaped()
+        # one view, same backward run: the factored form of dL_dsh is the dense one, exactly
+        masked = dgr._C.masked_color_gradient(aux["geom"], aux["dL_dcolors"])
+        one = dgr._C.sh_gradient_from_views(scene.means3D, cam.camera_center.reshape(1, 3), masked.reshape(1, -1), D, M)
+        assert torch.equal(one, d["dL_dsh"])
+        # the exchange object run on its own backward pass (float atomics make two backward runs differ in the
+        # last bits, hence a tolerance here)
+        fact = view_parallel.FactoredGradientExchange(P, M, dev, world_size=1)
+        _, _, aux2 = view_parallel.forward_backward(scene, cam, bg, lambda color: dL, fact, c["tanfovx"],
+                                                    c["tanfovy"])
+        fact.reduce(scene, cam, aux2)
+        torch.cuda.synchronize()
+        f = fact.shaped()
+        for name in view_parallel.BUCKET_FIELDS:
+            big = float(d[name].abs().max())
+            assert float((d[name] - f[name]).abs().max()) <= 1e-5 * big + 1e-12, name
+        # the mask is the forward pass's clamp flags
+        cc = dict(c, cam=cam_cpu)
+        o = oracle_forward(oracle, cc)
+        want = aux["dL_dcolors"].cpu().numpy() * (1 - o["clamped"].astype(np.float32))
+        np.testing.assert_array_equal(masked.cpu().numpy(), want)
+        if D > 0 and v == 0:
+            assert o["clamped"][o["radii"] > 0].any()
+        masked_rows.append(masked.reshape(-1).clone())
+        campos.append(cam.camera_center.reshape(3).clone())
+        dense_sum = d["dL_dsh"].clone() if dense_sum is None else dense_sum + d["dL_dsh"]
+    # gathered-buffer layout: one row per view holding [masked colour gradient | camera position | pad]
+    rows = torch.stack([torch.cat([m, cp, cp.new_zeros(1)]) for m, cp in zip(masked_rows, campos)])
+    got = dgr._C.sh_gradient_from_views(scene.means3D, rows[:, 3 * P:3 * P + 3], rows[:, :3 * P], D, M)
+    torch.cuda.synchronize()
+    assert torch.equal(got, dense_sum)
+    with pytest.raises(RuntimeError):
+        dgr._C.sh_gradient_from_views(scene.means3D, rows[:, 3 * P:3 * P + 3], rows[:, :3 * P], 3, 9)

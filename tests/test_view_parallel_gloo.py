@@ -34,6 +34,84 @@ def _worker(rank, world, port, P, M, ret):
         dist.destroy_process_group()
 
 
+class _Obj:
+    pass
+
+
+def _view_inputs(rank, P):
+    g = torch.Generator().manual_seed(100 + rank)
+    colors = torch.randn(P, 3, generator=g)
+    colors[rank::5] = 0.0  # Gaussians this view does not see
+    mask = (torch.rand(P, 3, generator=g) > 0.3).float()
+    campos = torch.randn(3, generator=g) * 4.0
+    return colors, mask, campos
+
+
+def _sh_sum(means, campos, colors, degree, M):
+    """Plain formulation of the summed SH gradient: sum over views of basis(direction) x colour gradient."""
+    from neuralgaussiansplatting_amd.sh_utils import sh_basis
+    P = means.shape[0]
+    acc = torch.zeros(P, M, 3)
+    for v in range(colors.shape[0]):
+        d = means - campos[v].reshape(1, 3)
+        B = sh_basis(degree, d / d.norm(dim=1, keepdim=True))
+        acc[:, :B.shape[1]] += B[:, :, None] * colors[v].reshape(P, 1, 3)
+    return acc
+
+
+def _factored_worker(rank, world, port, P, M, D, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # The two library calls of the exchange need a GPU; stand-ins with the same contracts let the
+        # collectives, buffer layout and strides be exercised on CPU.
+        def masked(geom, dL_dcolors, out=None):
+            out.copy_((dL_dcolors * geom).reshape(-1))
+            return out
+
+        def sh_from_views(means3D, campos, colors, degree, M_, out=None):
+            assert campos.shape == (world, 3) and colors.shape == (world, 3 * P)
+            out.copy_(_sh_sum(means3D, campos, colors, degree, M_))
+            return out
+
+        view_parallel._C.masked_color_gradient = masked
+        view_parallel._C.sh_gradient_from_views = sh_from_views
+        means = torch.randn(P, 3, generator=torch.Generator().manual_seed(7))
+        scene, cam = _Obj(), _Obj()
+        scene.means3D, scene.sh_degree = means, D
+        colors, mask, campos = _view_inputs(rank, P)
+        cam.camera_center = campos
+        ex = view_parallel.FactoredGradientExchange(P, M, torch.device("cpu"))
+        assert ex.skip_sh and ex.world == world
+        for i, (name, v) in enumerate(ex.views.items()):
+            v.copy_(torch.arange(v.numel(), dtype=torch.float32) * (rank + 1) + i)
+        ex.reduce(scene, cam, dict(geom=mask, dL_dcolors=colors))
+        ok = True
+        for i, (name, v) in enumerate(ex.views.items()):
+            want = torch.arange(v.numel(), dtype=torch.float32) * sum(r + 1 for r in range(world)) + i * world
+            ok = ok and torch.equal(v, want)
+        allv = [_view_inputs(r, P) for r in range(world)]
+        want_sh = _sh_sum(means, torch.stack([a[2] for a in allv]),
+                          torch.stack([(a[0] * a[1]).reshape(-1) for a in allv]), D, M)
+        sh = ex.shaped()
+        ok = ok and torch.equal(sh["dL_dsh"], want_sh) and sh["dL_dsh"].shape == (P, M, 3)
+        ok = ok and sh["dL_dopacity"].shape == (P, 1) and set(sh) == set(view_parallel.BUCKET_FIELDS)
+        ok = ok and ex.bytes_sent_per_rank() == 4 * (3 * P + 4 + 11 * P)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_factored_exchange_world2():
+    world, P, M, D = 2, 41, 16, 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_factored_worker, args=(world, port, P, M, D, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_bucket_all_reduce_world2():
     world, P, M = 2, 37, 16
     mgr = mp.Manager()
