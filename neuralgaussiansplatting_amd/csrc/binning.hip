@@ -15,7 +15,8 @@
 // owns a contiguous run of ceil(n/1024) entries.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, const uint32_t* __restrict__ in,
                                                                         uint32_t* __restrict__ out,
-                                                                        uint32_t* __restrict__ misc)
+                                                                        uint32_t* __restrict__ misc,
+                                                                        unsigned long long* mailbox)
 {
     __shared__ uint32_t wave_tot[SCAN_THREADS / 64];
     const int per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -39,7 +40,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
         out[i] = run;
         run += v;
     }
-    if (threadIdx.x == 0) misc[0] = total;
+    if (threadIdx.x == 0) {
+        misc[0] = total;
+        // The host is spinning on this word of pinned host memory (it holds ~0 until now): the instance count and
+        // the error flag reach it without a copy engine or an interrupt in between.
+        if (mailbox)
+            __hip_atomic_store(mailbox, ((unsigned long long)misc[1] << 32) | total, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // One workgroup per 256 Gaussians (the same blocks as the preprocess kernel).
@@ -115,10 +123,10 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t L, const uint6
 }
 
 void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* block_sums, uint32_t* block_offs,
-                                uint32_t* misc)
+                                uint32_t* misc, unsigned long long* mailbox)
 {
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblocks, block_sums, block_offs,
-                       misc);
+                       misc, mailbox);
 }
 
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const float* depth, const uint32_t* tiles,

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/ngs_rasterizer.h"
+#include <chrono>
 #include "ngs_common.h"
 
 static thread_local char g_err[512] = "";
@@ -149,6 +150,57 @@ static NgsCamera make_camera(int W, int H, float tanx, float tany, const float* 
     return c;
 }
 
+// One 64-bit word of coherent pinned host memory per calling thread, written by the scan kernel and polled by the
+// host (see ngs_rasterize_forward).  Allocated on first use and kept for the life of the thread's process;
+// NGS_NO_MAILBOX=1 disables it.
+struct Mailbox {
+    unsigned long long* host;
+    unsigned long long* dev;
+};
+
+static Mailbox* mailbox_get()
+{
+    static thread_local Mailbox mb = {nullptr, nullptr};
+    static thread_local int state = 0;  // 0 = not tried, 1 = ready, -1 = unavailable
+    if (state == 0) {
+        state = -1;
+        const char* off = getenv("NGS_NO_MAILBOX");
+        if (!(off && off[0] == '1')) {
+            void* h = nullptr;
+            void* d = nullptr;
+            if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) ==
+                    hipSuccess &&
+                hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                mb.host = (unsigned long long*)h;
+                mb.dev = (unsigned long long*)d;
+                state = 1;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+    return state == 1 ? &mb : nullptr;
+}
+
+// Spins until the scan kernel has posted its word; false after two seconds without it.
+static bool mailbox_wait(Mailbox* mb, uint32_t out[2])
+{
+    if (!mb) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        const unsigned long long v = __atomic_load_n(mb->host, __ATOMIC_ACQUIRE);
+        if (v != ~0ull) {
+            out[0] = (uint32_t)v;
+            out[1] = (uint32_t)(v >> 32);
+            return true;
+        }
+        if ((spins & 1023u) == 1023u &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+            return false;
+        __builtin_ia32_pause();
+    }
+}
+
 extern "C" const char* ngs_last_error(void) { return g_err; }
 
 extern "C" size_t ngs_required_geometry_bytes(int P) { return ngs_geom_layout((size_t)(P > 0 ? P : 0)).total; }
@@ -228,14 +280,21 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     prof_end(ps, ST_PREPROCESS, st);
     NGS_STAGE("preprocess");
     prof_begin(ps, ST_SCAN, st);
-    ngs_launch_scan_block_sums(st, nblocks, block_sums, block_offs, misc);
+    Mailbox* mb = mailbox_get();
+    if (mb) __atomic_store_n(mb->host, ~0ull, __ATOMIC_RELEASE);
+    ngs_launch_scan_block_sums(st, nblocks, block_sums, block_offs, misc, mb ? mb->dev : nullptr);
     prof_end(ps, ST_SCAN, st);
     NGS_STAGE("scan");
 
-    // The instance count sizes the binning buffer: one blocking 8-byte read-back.
+    // The instance count sizes the binning buffer, so the host has to wait for it here (the reference blocks on a
+    // device-to-host copy at the same point, rasterizer_impl.cu:281).  The scan kernel posts the 8 bytes straight
+    // into pinned host memory and the host spins on them; if they do not arrive (a failed kernel, a platform
+    // without coherent host memory) the wait falls back to a copy and a stream synchronisation.
     uint32_t host_misc[2] = {0, 0};
-    NGS_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, st));
-    NGS_HIP(hipStreamSynchronize(st));
+    if (!mailbox_wait(mb, host_misc)) {
+        NGS_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, st));
+        NGS_HIP(hipStreamSynchronize(st));
+    }
     if (host_misc[1] & 1u) return fail("ngs_rasterize_forward", "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (host_misc[0] > 0x7fffffffu) return fail("ngs_rasterize_forward", "more than 2^31-1 tile instances");
     const int64_t R = (int64_t)host_misc[0];

@@ -131,8 +131,10 @@ void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* 
                                uint32_t* block_sums, uint32_t* misc);
 void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const float* view, uint8_t* present);
 // binning.hip
+// mailbox: device-visible address of a 64-bit word in pinned host memory that receives (error flag << 32 | total),
+// or NULL.
 void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* block_sums, uint32_t* block_offs,
-                                uint32_t* misc);
+                                uint32_t* misc, unsigned long long* mailbox);
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const float* depth, const uint32_t* tiles,
                           const uint32_t* block_offs, int grid_x, uint64_t* keys, uint32_t* vals);
 void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint64_t* keys, int T, uint2* ranges);

@@ -6,8 +6,8 @@
 //    the per-pixel last-contributor indices the forward pass stored) instead
 //    of at the end of the tile's list: entries behind it are skipped by every
 //    pixel in the reference too (backward.cu:486-488), so they are never staged.
-//  * Each wave ballots which staged splats can reach its 16x4 strip AND lie in
-//    front of the strip's own deepest contributor, and walks only those.
+//  * Each wave ballots which staged splats can reach its 8x8 block AND lie in
+//    front of the block's own deepest contributor, and walks only those.
 //  * Reduction: the reference issues nine global float atomics per (pixel,
 //    splat) pair.  Here all 64 lanes of a wave handle the same splat in
 //    lock-step, so the nine partials are summed across the wave in registers
@@ -66,18 +66,18 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int tx = tile % grid_x, ty = tile / grid_x;
-    const int px = tx * NGS_TILE_W + (tid & 15), py = ty * NGS_TILE_H + (tid >> 4);
+    const int px = tx * NGS_TILE_W + tile_local_x(tid), py = ty * NGS_TILE_H + tile_local_y(tid);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const float sx0 = (float)(tx * NGS_TILE_W), sx1 = sx0 + (NGS_TILE_W - 1);
-    const float sy0 = (float)(ty * NGS_TILE_H + wave * 4), sy1 = sy0 + 3.0f;
+    const float sx0 = (float)(tx * NGS_TILE_W + (wave & 1) * NGS_WAVE_W), sx1 = sx0 + (NGS_WAVE_W - 1);
+    const float sy0 = (float)(ty * NGS_TILE_H + (wave >> 1) * NGS_WAVE_H), sy1 = sy0 + (NGS_WAVE_H - 1);
     const uint2 range = ranges[tile];
 
     const size_t tp = (size_t)tile * NGS_TILE_PIX + tid;
     const float T_final = inside ? final_T[tp] : 0.0f;
     float T = T_final;
     const uint32_t last_contributor = inside ? n_contrib[tp] : 0u;
-    // deepest contributor of this strip (wave) and of the tile
+    // deepest contributor of this block (wave) and of the tile
     uint32_t wmax = last_contributor;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o, 64));

@@ -33,5 +33,14 @@ __device__ __forceinline__ bool splat_touches(float sx, float sy, float2 h, floa
     return !outside;
 }
 
+// Pixel layout of a tile's 256 threads: each wave64 covers one 8x8 pixel block (2x2 blocks per 16x16 tile), lanes
+// row-major inside the block.  A square block is touched by fewer splats than a 16x4 strip of the same area, and a
+// touching splat covers more of its pixels.  final_T / n_contrib are stored per tile in thread order, so the
+// forward and backward kernels (and the state decoder) share this mapping.
+#define NGS_WAVE_W 8
+#define NGS_WAVE_H 8
+__device__ __forceinline__ int tile_local_x(int tid) { return ((tid >> 6) & 1) * NGS_WAVE_W + (tid & 7); }
+__device__ __forceinline__ int tile_local_y(int tid) { return (tid >> 7) * NGS_WAVE_H + ((tid >> 3) & 7); }
+
 // Index of the lowest set bit of a non-zero wave mask.
 __device__ __forceinline__ int lowest_lane(unsigned long long m) { return __builtin_ctzll(m); }

@@ -1,20 +1,20 @@
 // Per-tile front-to-back alpha compositing (forward).  One 256-thread
-// workgroup per 16x16 tile, four wave64s each covering a 16x4 pixel strip.
+// workgroup per 16x16 tile, four wave64s each covering a 8x8 pixel block.
 //
 // The four waves of a tile run DECOUPLED: there is no workgroup barrier in the
 // kernel.  Each wave walks the tile's depth-sorted list on its own, 64 splats
 // at a time: lane l fetches splat l of the batch (the next batch's loads are
 // issued before the current one is processed), tests whether the splat can
-// reach the wave's strip at all (opacity-aware bounding box, render_common.h),
+// reach the wave's block at all (opacity-aware bounding box, render_common.h),
 // parks the 48-byte record in the wave's private LDS slice, and the wave then
 // walks only the set bits of the wave-uniform ballot mask, reading each record
 // back as three broadcast LDS loads.  A wave whose 64 pixels are all saturated
-// simply leaves; nobody waits for the slowest strip of the tile.
+// simply leaves; nobody waits for the slowest block of the tile.
 //
 // Per-pixel arithmetic and its order follow cuda_rasterizer/forward.cu:261-374
 // of the reference; the per-pixel body is branch-free (predicated).  Skipping a
-// splat whose box misses the strip cannot change any pixel because every pixel
-// of the strip would have failed the alpha test.
+// splat whose box misses the block cannot change any pixel because every pixel
+// of the block would have failed the alpha test.
 #include "render_common.h"
 
 __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
@@ -27,12 +27,12 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int tx = tile % grid_x, ty = tile / grid_x;
-    const int px = tx * NGS_TILE_W + (tid & 15), py = ty * NGS_TILE_H + (tid >> 4);
+    const int px = tx * NGS_TILE_W + tile_local_x(tid), py = ty * NGS_TILE_H + tile_local_y(tid);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    // this wave's pixel strip
-    const float sx0 = (float)(tx * NGS_TILE_W), sx1 = sx0 + (NGS_TILE_W - 1);
-    const float sy0 = (float)(ty * NGS_TILE_H + wave * 4), sy1 = sy0 + 3.0f;
+    // this wave's pixel block
+    const float sx0 = (float)(tx * NGS_TILE_W + (wave & 1) * NGS_WAVE_W), sx1 = sx0 + (NGS_WAVE_W - 1);
+    const float sy0 = (float)(ty * NGS_TILE_H + (wave >> 1) * NGS_WAVE_H), sy1 = sy0 + (NGS_WAVE_H - 1);
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     float4(*rec)[3] = s_rec[wave];
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
         nc = r[2].x;
     }
     for (int base = 0; base < n; base += 64) {
-        if (__ballot(!done) == 0ull) break;  // every pixel of the strip is saturated (or outside the image)
+        if (__ballot(!done) == 0ull) break;  // every pixel of the block is saturated (or outside the image)
         const float4 a = na, b = nb;
         const float c = nc;
         const bool have = base + lane < n;
