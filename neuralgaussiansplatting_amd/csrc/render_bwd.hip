@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     const float4* __restrict__ splat_rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ acc)
 {
-    // record k: [0] = {x, y, reach x, reach y}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
+    // record k: [0] = {x, y, ln(255 opacity), -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
     __shared__ float4 s_rec[NGS_TILE_PIX][3];
     __shared__ float s_acc[NGS_TILE_PIX][ACC_USED];
     __shared__ uint32_t s_wmax[NGS_TILE_PIX / 64];
@@ -118,8 +118,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             const float4 a = gr[0];
             const float4 b = gr[1];
             const float c = gr[2].x;
-            const float2 h = splat_half_extent(a.z, a.w, b.x, b.y);
-            s_rec[tid][0] = make_float4(a.x, a.y, h.x, h.y);
+            s_rec[tid][0] = make_float4(a.x, a.y, splat_tau(b.y), 0.0f);
             s_rec[tid][1] = make_float4(a.z, a.w, b.x, b.y);
             s_rec[tid][2] = make_float4(b.z, b.w, c, __uint_as_float(id));
         }
@@ -131,7 +130,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             bool reach = false;
             if (mine < nb && (uint32_t)(first - mine) < wmax) {
                 const float4 p = s_rec[mine][0];
-                reach = splat_touches(p.x, p.y, make_float2(p.z, p.w), sx0, sx1, sy0, sy1);
+                const float4 q = s_rec[mine][1];
+                reach = splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, sx0, sx1, sy0, sy1);
             }
             unsigned long long mask = __ballot(reach);
             while (mask) {

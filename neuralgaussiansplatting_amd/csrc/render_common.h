@@ -2,35 +2,36 @@
 #pragma once
 #include "ngs_common.h"
 
-// Conservative screen-space half extents of the region where a splat can pass
-// the reference's per-pixel tests (forward.cu:335-345): a pixel contributes
-// only if power <= 0 and opacity * exp(power) >= 1/255, i.e. power >= -tau with
-// tau = ln(255 * opacity).  {d : 0.5 d^T Q d <= tau} is an ellipse whose
-// bounding box has half widths sqrt(2 tau inv(Q)_xx), sqrt(2 tau inv(Q)_yy),
-// Q = [[a, b], [b, c]] being the conic.  The box is inflated slightly so that
-// rounding can never drop a pair the exact test would keep; a conic that is
-// not positive definite (or not finite) gets an infinite box.  Culling with
-// this box therefore never changes a result, it only skips pairs that would
-// have failed the alpha test.
-__device__ __forceinline__ float2 splat_half_extent(float a, float b, float c, float opacity)
-{
-    const float det = a * c - b * b;
-    float hx = __builtin_inff(), hy = __builtin_inff();
-    if (det > 0.0f && a > 0.0f && c > 0.0f) {
-        const float s = 2.0f * logf(255.0f * opacity) / det;
-        // 1 % + half a pixel: far above the float error of the per-pixel power (<= ~0.2 % of the extent even
-        // for needle-shaped splats whose quadratic-form terms cancel heavily)
-        hx = sqrtf(fmaxf(s * c, 0.0f)) * 1.01f + 0.5f;
-        hy = sqrtf(fmaxf(s * a, 0.0f)) * 1.01f + 0.5f;
-    }
-    return make_float2(hx, hy);
-}
+// Wave-level culling of (splat, pixel block) pairs.  A pixel passes the reference's per-pixel tests
+// (forward.cu:335-345) only if power <= 0 and opacity * exp(power) >= 1/255, i.e. q(d) <= 2 tau with
+// q(d) = a dx^2 + 2 b dx dy + c dy^2 (the conic's quadratic form at the pixel's offset d from the centre) and
+// tau = ln(255 * opacity).  splat_reaches() minimises q over the continuous rectangle spanned by a wave's
+// pixel block (inside -> 0, else the best of the four edges, each a clamped 1-D parabola) and keeps the pair
+// unless even that minimum fails the test by a margin: 0.01 in tau plus 1e-5 of the magnitude of the form's
+// terms over the block, about thirty times the rounding error of the per-pixel evaluation, however badly the
+// terms cancel (needle-shaped splats).  A conic that is not positive definite (or not finite) is never culled.
+// Culling therefore never changes a result; it only skips pairs every pixel of the block would have rejected.
+__device__ __forceinline__ float splat_tau(float opacity) { return logf(255.0f * opacity); }
 
-// True unless the splat's box provably misses the pixel rectangle [x0,x1] x [y0,y1].
-__device__ __forceinline__ bool splat_touches(float sx, float sy, float2 h, float x0, float x1, float y0, float y1)
+__device__ __forceinline__ bool splat_reaches(float sx, float sy, float a, float b, float c, float tau, float x0,
+                                              float x1, float y0, float y1)
 {
-    const bool outside = (sx + h.x < x0) || (sx - h.x > x1) || (sy + h.y < y0) || (sy - h.y > y1);
-    return !outside;
+    if (!(a > 0.0f && c > 0.0f && a * c - b * b > 0.0f)) return true;
+    const float xl = x0 - sx, xh = x1 - sx, yl = y0 - sy, yh = y1 - sy;
+    const bool inside = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
+    const float tb = 2.0f * b;
+    // edges x = xl, x = xh: q is minimised over y at -b x / c, clamped to the edge
+    const float ya = fminf(fmaxf(-b * xl / c, yl), yh), yb = fminf(fmaxf(-b * xh / c, yl), yh);
+    const float q0 = a * xl * xl + tb * xl * ya + c * ya * ya;
+    const float q1 = a * xh * xh + tb * xh * yb + c * yb * yb;
+    // edges y = yl, y = yh
+    const float xa = fminf(fmaxf(-b * yl / a, xl), xh), xb = fminf(fmaxf(-b * yh / a, xl), xh);
+    const float q2 = a * xa * xa + tb * xa * yl + c * yl * yl;
+    const float q3 = a * xb * xb + tb * xb * yh + c * yh * yh;
+    const float qmin = inside ? 0.0f : fminf(fminf(q0, q1), fminf(q2, q3));
+    const float mx = fmaxf(fabsf(xl), fabsf(xh)), my = fmaxf(fabsf(yl), fabsf(yh));
+    const float mag = a * mx * mx + fabsf(tb) * mx * my + c * my * my;
+    return 0.5f * qmin <= tau + 0.01f + 1e-5f * mag;
 }
 
 // Pixel layout of a tile's 256 threads: each wave64 covers one 8x8 pixel block (2x2 blocks per 16x16 tile), lanes

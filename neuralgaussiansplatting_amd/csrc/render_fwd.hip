@@ -5,7 +5,7 @@
 // kernel.  Each wave walks the tile's depth-sorted list on its own, 64 splats
 // at a time: lane l fetches splat l of the batch (the next batch's loads are
 // issued before the current one is processed), tests whether the splat can
-// reach the wave's block at all (opacity-aware bounding box, render_common.h),
+// reach the wave's block at all (minimum of its quadratic form over the block against the opacity threshold, render_common.h),
 // parks the 48-byte record in the wave's private LDS slice, and the wave then
 // walks only the set bits of the wave-uniform ballot mask, reading each record
 // back as three broadcast LDS loads.  A wave whose 64 pixels are all saturated
@@ -13,7 +13,7 @@
 //
 // Per-pixel arithmetic and its order follow cuda_rasterizer/forward.cu:261-374
 // of the reference; the per-pixel body is branch-free (predicated).  Skipping a
-// splat whose box misses the block cannot change any pixel because every pixel
+// splat culled this way cannot change any pixel because every pixel
 // of the block would have failed the alpha test.
 #include "render_common.h"
 
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
         }
         bool reach = false;
         if (have) {
-            reach = splat_touches(a.x, a.y, splat_half_extent(a.z, a.w, b.x, b.y), sx0, sx1, sy0, sy1);
+            reach = splat_reaches(a.x, a.y, a.z, a.w, b.x, splat_tau(b.y), sx0, sx1, sy0, sy1);
             if (reach) {
                 rec[lane][0] = make_float4(a.x, a.y, 0.0f, 0.0f);
                 rec[lane][1] = make_float4(a.z, a.w, b.x, b.y);
