@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
                 const float4 col = s_rec[j][2];
                 const float dx = p.x - pxf, dy = p.y - pyf;
                 const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
-                const float G = expf(power);
+                const float G = exp_nonpos(power);
                 const float alpha = fminf(0.99f, q.w * G);
                 const bool live = pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__ballot(live) == 0ull) continue;  // wave-uniform
@@ -156,8 +156,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
                 const float nrec_r = last_alpha * last_r + (1.f - last_alpha) * rec_r;
                 const float nrec_g = last_alpha * last_g + (1.f - last_alpha) * rec_g;
                 const float nrec_b = last_alpha * last_b + (1.f - last_alpha) * rec_b;
-                float dL_dalpha = 0.0f;
-                dL_dalpha += (col.x - nrec_r) * dpr;
+                float dL_dalpha = (col.x - nrec_r) * dpr;
                 dL_dalpha += (col.y - nrec_g) * dpg;
                 dL_dalpha += (col.z - nrec_b) * dpb;
                 dL_dalpha *= Tn;

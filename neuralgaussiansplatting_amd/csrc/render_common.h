@@ -43,5 +43,19 @@ __device__ __forceinline__ bool splat_reaches(float sx, float sy, float a, float
 __device__ __forceinline__ int tile_local_x(int tid) { return ((tid >> 6) & 1) * NGS_WAVE_W + (tid & 7); }
 __device__ __forceinline__ int tile_local_y(int tid) { return (tid >> 7) * NGS_WAVE_H + ((tid >> 3) & 7); }
 
+// exp(x) for the compositing kernels, whose argument is the Gaussian exponent: never positive when it is used.
+// Same operation sequence as the device library's expf (argument reduction by log2(e) in two parts, v_exp_f32,
+// ldexp), so the result is bit-identical for x <= 0, but without expf's two range guards: for x below -103.3
+// expf returns exactly 0 while this returns at most a denormal (alpha then fails the 1/255 test either way),
+// and positive arguments are rejected by the caller before the value is used.
+__device__ __forceinline__ float exp_nonpos(float x)
+{
+    const float log2e_hi = __builtin_bit_cast(float, 0x3fb8aa3bu), log2e_lo = __builtin_bit_cast(float, 0x32a5705fu);
+    const float ph = x * log2e_hi;
+    const float pl = fmaf(x, log2e_lo, fmaf(x, log2e_hi, -ph));
+    const float n = rintf(ph);
+    return ldexpf(__builtin_amdgcn_exp2f((ph - n) + pl), (int)n);
+}
+
 // Index of the lowest set bit of a non-zero wave mask.
 __device__ __forceinline__ int lowest_lane(unsigned long long m) { return __builtin_ctzll(m); }

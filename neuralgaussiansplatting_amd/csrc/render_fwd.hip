@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
             const float4 col = rec[j][2];
             const float dx = p.x - pxf, dy = p.y - pyf;
             const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
-            const float alpha = fminf(0.99f, q.w * expf(power));
+            const float alpha = fminf(0.99f, q.w * exp_nonpos(power));
             const float test_T = T * (1 - alpha);
             const bool hit = !done && power <= 0.0f && !(alpha < 1.0f / 255.0f);
             const bool stop = hit && test_T < 0.0001f;
