@@ -17,7 +17,9 @@
  *
  * Return value: 0 on success, non-zero on failure; ngs_last_error() then
  * returns a message (thread-local storage, valid until the next call on that
- * thread).  Nothing is retained by the library between calls.
+ * thread).  Nothing is retained by the library between calls except one 64-byte
+ * word of pinned host memory per calling thread, through which the instance
+ * count reaches the host (NGS_NO_MAILBOX=1 in the environment disables it).
  */
 #ifndef NGS_RASTERIZER_H
 #define NGS_RASTERIZER_H
@@ -39,8 +41,8 @@ typedef char* (*ngs_alloc_fn)(void* ctx, size_t bytes);
  * P Gaussians, D active SH degree, M SH coefficients per Gaussian in `shs`
  * ([P][M][3]).  viewmatrix / projmatrix are 4x4 in the reference's row-vector
  * memory order; out_color is [3][height][width]; radii is [P] or NULL.
- * Blocks the host once (4-byte read-back of the instance count, as the
- * reference does at rasterizer_impl.cu:281).  *num_rendered receives the
+ * Blocks the host once (it waits for the instance count, as the reference does
+ * at rasterizer_impl.cu:281).  *num_rendered receives the
  * number of (Gaussian, tile) instances, the reference's return value.
  * With prefiltered != 0, a Gaussian failing the near-plane test makes the call
  * fail (the reference aborts the kernel, auxiliary.h:156-160).  With debug != 0
