@@ -34,7 +34,7 @@ from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C  # noqa: 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
-def stage_bytes(P, R, W, H, D, M, vis):
+def stage_bytes(P, R, W, H, D, M, vis, views=1):
     """Algorithmic HBM bytes of one launch of each stage (per-unit figures in DESIGN.md)."""
     c = (D + 1) ** 2
     T = ((W + 15) // 16) * ((H + 15) // 16)
@@ -51,6 +51,11 @@ def stage_bytes(P, R, W, H, D, M, vis):
         "zero_accumulator": 64 * P,
         "render_bwd": 112 * R + 8 * T + 20 * W * H,
         "preprocess_bwd": 4 * P + vP * (105 + 12 * c) + P * (92 + 12 * M),
+        # training-step companions: per iteration (the Adam stages are several launches)
+        "sh_gradient_from_views": 25 * P + 12 * P + views * 12 * P + 12 * M * P,
+        "l1_ssim_loss": 11 * 12 * W * H,
+        "adam_identity_groups": 28 * (3 * P + 3 * M * P),
+        "adam_activated_groups": 32 * 8 * P + 40 * P,
     }
 
 
@@ -87,6 +92,9 @@ def main():
                          "11 floats per Gaussian (default), or one dense all-reduce of all 59")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo lets several ranks share one GPU to rehearse the N > 1 path on a one-GPU box")
+    ap.add_argument("--train-steps", type=int, default=None,
+                    help="full training iterations (render + L1/D-SSIM loss + backward + exchange + Adam) timed in a "
+                         "second loop for the train iters/s figure; default: --steps, 0 to skip")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
@@ -164,6 +172,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- second loop: whole training iterations ----
+    train_steps = args.steps if args.train_steps is None else args.train_steps
+    train = None
+    if train_steps > 0:
+        from neuralgaussiansplatting_amd import train_step
+        trainer = train_step.GaussianTrainer(scene, dev, factored_exchange=args.exchange == "factored")
+        gt = torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(4321 + rank)).to(dev)
+        for _ in range(max(args.warmup, 1)):
+            trainer.step(cam, gt, bg, tanx, tany)
+        _C.profile_enable(not args.no_stage_timing)
+        _C.profile_read(reset=True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(train_steps):
+            trainer.step(cam, gt, bg, tanx, tany)
+        fence()
+        t_train = time.perf_counter() - t0
+        train_stages = _C.profile_read(reset=True)
+        _C.profile_enable(False)
+        note("training iterations done")
+        if world > 1:
+            t = torch.tensor([t_train], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_train = float(t.item())
+        train = (t_train, train_stages)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * W * H * args.steps / elapsed / 1e6
@@ -174,7 +208,7 @@ def main():
             cam.full_proj_transform, tanx, tany, H, W, scene.shs, D, cam.camera_center, False, False)
         stt = decode_state(_C, P, Rr, W, H, geom, binning, img)
         per_tile = (stt["ranges"][:, 1] - stt["ranges"][:, 0]).astype(np.int64)
-        nbytes = stage_bytes(P, R, W, H, D, M, vis)
+        nbytes = stage_bytes(P, R, W, H, D, M, vis, views=world)
         stage_out, dom, dom_ms = {}, None, 0.0
         for name, (tot, cnt) in stages.items():
             if cnt == 0:
@@ -199,6 +233,21 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene_cpu, synthetic.make_view(W, H, index=0, count=8), W, H, D, tanx, tany, dL)
+        train_out = None
+        if train is not None:
+            t_train, train_stages = train
+            per_iter = {}
+            for name, (tot, cnt) in train_stages.items():
+                if cnt:
+                    ms = tot / train_steps
+                    per_iter[name] = {"ms_per_iter": round(ms, 4), "launches_per_iter": round(cnt / train_steps, 2),
+                                      "GB_per_s": round(nbytes[name] / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
+            train_out = {"iters_per_s": round(world * train_steps / t_train, 2),
+                         "ms_per_iter": round(t_train / train_steps * 1e3, 4), "steps": train_steps,
+                         "what": "lr schedule + render + fused L1/D-SSIM loss + backward + %sfused Adam with "
+                                 "activations and densification statistics, fixed random target image"
+                                 % ("gradient exchange + " if world > 1 else ""),
+                         "stages": per_iter}
         line = {
             "metric": "fwd+bwd Mpixels/s (rasterizer forward+backward, 1080p / 3M Gaussians per GPU)"
                       if args.config == "c4" else "fwd+bwd Mpixels/s (rasterizer forward+backward)",
@@ -215,7 +264,7 @@ def main():
                        "instances_per_tile_max": int(per_tile.max()),
                        "last_contributor_per_pixel_mean": round(float(stt["n_contrib"].mean()), 1),
                        "parallelism": "view-sharded dp%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "stages": stage_out,
+            "roofline": roofline, "cpu_baseline": cpu, "stages": stage_out, "train": train_out,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -109,6 +109,41 @@ int ngs_sh_gradient_from_views(int P, int D, int M, int V, const float* means3D,
                                float* dL_dsh, void* stream);
 
 /*
+ * Training-step companions of the rasterizer.  The reference has no native counterpart: it runs these parts of an
+ * iteration as chains of PyTorch operators (file:line below).
+ *
+ * ngs_l1_ssim_loss: loss = (1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)) with the 11x11 Gaussian
+ * window (sigma 1.5, zero padding) of utils/loss_utils.py:17-63, combined as at train.py:90-92, and its gradient wrt
+ * `image`.  image, gt_image, dL_dimage: [3][height][width]; loss_terms: 3 floats on the device = {L1 mean, SSIM
+ * mean, loss}; workspace: ngs_loss_workspace_bytes(width, height) bytes of device memory.
+ *
+ * ngs_adam_step: torch.optim.Adam's update (no weight decay, no amsgrad; gaussian_model.py:275) of a flat tensor of
+ * n floats whose activation is the identity (positions, SH coefficients).  Elements whose index modulo `period` is
+ * below `head` use lr_head, the rest lr_tail: with period = 3*M, head = 3 one call covers the reference's "f_dc"
+ * and "f_rest" groups (gaussian_model.py:262-263) on a single [P][M][3] tensor.  `step` counts from 1.  The
+ * gradient is multiplied by grad_scale first (1/views for a mean over a view batch).  Arrays 16-byte aligned.
+ *
+ * ngs_adam_step_activated: the same update for opacity, scaling and rotation (index 0, 1, 2 of each array of
+ * pointers; [P], [P][3], [P][4]), whose raw values pass through sigmoid, exp and normalise
+ * (gaussian_model.py:36-43, 113-141): grad[] is the gradient wrt the ACTIVATED value, as ngs_rasterize_backward
+ * returns it; the activation's backward is applied here, raw[] is updated in place and activated[] receives the new
+ * activated values for the next forward pass.  When xyz_gradient_accum is not NULL the densification statistics
+ * are updated as well for Gaussians with radii > 0: xyz_gradient_accum += |dL_dmean2D.xy|, denom += 1
+ * (gaussian_model.py:550-552), max_radii2D = max(max_radii2D, radii) (train.py:115).
+ */
+size_t ngs_loss_workspace_bytes(int width, int height);
+int ngs_l1_ssim_loss(int width, int height, float lambda_dssim, const float* image, const float* gt_image,
+                     float* workspace, float* loss_terms, float* dL_dimage, void* stream);
+int ngs_adam_step(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr_head,
+                  double lr_tail, int period, int head, double beta1, double beta2, double eps, int step,
+                  float grad_scale, void* stream);
+int ngs_adam_step_activated(int P, float* const raw[3], const float* const grad[3], float* const exp_avg[3],
+                            float* const exp_avg_sq[3], float* const activated[3], const double lr[3], double beta1,
+                            double beta2, double eps, int step, float grad_scale, const float* dL_dmean2D,
+                            const int* radii, float* xyz_gradient_accum, float* denom, int* max_radii2D,
+                            void* stream);
+
+/*
  * Introspection for parity tests: byte offsets (relative to the 256-byte
  * aligned base of each buffer) of the intermediate arrays, in this order:
  *  geometry[10]: splat_record(16 floats per Gaussian: x, y, conic a, b, c, opacity, r, g, b, 7 unused),
@@ -123,7 +158,7 @@ int ngs_state_layout(int P, long long R, int width, int height, size_t* geometry
 
 /*
  * Per-stage timing with HIP events recorded on the caller's stream around each
- * stage of ngs_rasterize_forward / _backward.  No counterpart in the reference
+ * stage of ngs_rasterize_forward / _backward and around the other entry points' kernels.  No counterpart in the reference
  * (its only timer is a torch.cuda.Event pair around a whole iteration,
  * train.py:44-45,67,95).  One device per process; not thread-safe.
  * ngs_profile_read synchronises with the recorded events and returns, per

@@ -40,12 +40,13 @@ static int fail(const char* what, const char* detail)
 // ---------------------------------------------------------------------------
 enum {
     ST_PREPROCESS, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SEGSORT, ST_RENDER_FWD,
-    ST_BWD_ZERO, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT
+    ST_BWD_ZERO, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_SH_VIEWS, ST_LOSS, ST_ADAM_FLAT, ST_ADAM_ACTIVATED, ST_COUNT
 };
 static const char* const g_stage_names[ST_COUNT] = {
     "preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort_tile_bits", "tile_ranges", "segment_sort_depth",
     "render_fwd",
-    "zero_accumulator", "render_bwd", "preprocess_bwd"};
+    "zero_accumulator", "render_bwd", "preprocess_bwd", "sh_gradient_from_views", "l1_ssim_loss", "adam_identity_groups",
+    "adam_activated_groups"};
 #define PROF_RING 32
 struct ProfSlot {
     hipEvent_t ev[ST_COUNT][2];
@@ -404,7 +405,10 @@ extern "C" int ngs_masked_color_gradient(int P, const char* geom_buffer, const f
     if (!geom_buffer || !dL_dcolor || !out) return fail("ngs_masked_color_gradient", "missing required pointer");
     const GeomLayout gl = ngs_geom_layout((size_t)P);
     const char* gb = ngs_align_ptr((char*)geom_buffer);
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_SH_VIEWS, (hipStream_t)stream);
     ngs_launch_masked_color((hipStream_t)stream, P, (const uint8_t*)(gb + gl.clamped), dL_dcolor, out);
+    prof_end(ps, ST_SH_VIEWS, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("stage masked colour gradient", hipGetErrorString(e));
     return 0;
@@ -423,10 +427,93 @@ extern "C" int ngs_sh_gradient_from_views(int P, int D, int M, int V, const floa
         return fail("ngs_sh_gradient_from_views", "missing required pointer");
     if (campos_stride < 3 || view_stride < 3LL * P)
         return fail("ngs_sh_gradient_from_views", "view strides shorter than one view's data");
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_SH_VIEWS, (hipStream_t)stream);
     ngs_launch_sh_from_views((hipStream_t)stream, P, D, M, V, means3D, campos, campos_stride, dL_dcolor_views,
                              view_stride, dL_dsh);
+    prof_end(ps, ST_SH_VIEWS, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("stage SH gradient from views", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" size_t ngs_loss_workspace_bytes(int width, int height)
+{
+    return width > 0 && height > 0 ? ngs_loss_workspace_floats(width, height) * sizeof(float) : 0;
+}
+
+extern "C" int ngs_l1_ssim_loss(int width, int height, float lambda_dssim, const float* image, const float* gt_image,
+                                float* workspace, float* loss_terms, float* dL_dimage, void* stream)
+{
+    g_err[0] = 0;
+    if (width <= 0 || height <= 0) return fail("ngs_l1_ssim_loss", "bad sizes");
+    if (!image || !gt_image || !workspace || !loss_terms || !dL_dimage)
+        return fail("ngs_l1_ssim_loss", "missing required pointer");
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_LOSS, (hipStream_t)stream);
+    ngs_launch_l1_ssim((hipStream_t)stream, width, height, lambda_dssim, image, gt_image, workspace, loss_terms,
+                       dL_dimage);
+    prof_end(ps, ST_LOSS, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("stage image loss", hipGetErrorString(e));
+    return 0;
+}
+
+static bool adam_args_ok(double beta1, double beta2, double eps, int step)
+{
+    return beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0 && step >= 1;
+}
+
+extern "C" int ngs_adam_step(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                             double lr_head, double lr_tail, int period, int head, double beta1, double beta2,
+                             double eps, int step, float grad_scale, void* stream)
+{
+    g_err[0] = 0;
+    if (n < 0 || period < 1 || head < 0 || head > period) return fail("ngs_adam_step", "bad sizes");
+    if (!adam_args_ok(beta1, beta2, eps, step)) return fail("ngs_adam_step", "bad Adam constants or step < 1");
+    if (n == 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail("ngs_adam_step", "missing required pointer");
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 != 0)
+        return fail("ngs_adam_step", "arrays must be 16-byte aligned");
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_ADAM_FLAT, (hipStream_t)stream);
+    ngs_launch_adam_flat((hipStream_t)stream, n, param, grad, exp_avg, exp_avg_sq, lr_head, lr_tail, period, head,
+                         beta1, beta2, eps, step, grad_scale);
+    prof_end(ps, ST_ADAM_FLAT, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("stage Adam", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int ngs_adam_step_activated(int P, float* const raw[3], const float* const grad[3],
+                                       float* const exp_avg[3], float* const exp_avg_sq[3],
+                                       float* const activated[3], const double lr[3], double beta1, double beta2,
+                                       double eps, int step, float grad_scale, const float* dL_dmean2D,
+                                       const int* radii, float* xyz_gradient_accum, float* denom, int* max_radii2D,
+                                       void* stream)
+{
+    g_err[0] = 0;
+    if (P < 0) return fail("ngs_adam_step_activated", "bad size");
+    if (!adam_args_ok(beta1, beta2, eps, step))
+        return fail("ngs_adam_step_activated", "bad Adam constants or step < 1");
+    if (P == 0) return 0;
+    if (!raw || !grad || !exp_avg || !exp_avg_sq || !activated || !lr)
+        return fail("ngs_adam_step_activated", "missing required pointer");
+    for (int i = 0; i < 3; i++)
+        if (!raw[i] || !grad[i] || !exp_avg[i] || !exp_avg_sq[i] || !activated[i])
+            return fail("ngs_adam_step_activated", "missing required pointer");
+    if (((uintptr_t)raw[2] | (uintptr_t)grad[2] | (uintptr_t)exp_avg[2] | (uintptr_t)exp_avg_sq[2] |
+         (uintptr_t)activated[2]) % 16 != 0)
+        return fail("ngs_adam_step_activated", "rotation arrays must be 16-byte aligned");
+    if (xyz_gradient_accum && (!dL_dmean2D || !radii || !denom || !max_radii2D))
+        return fail("ngs_adam_step_activated", "densification statistics need dL_dmean2D, radii, denom, max_radii2D");
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_ADAM_ACTIVATED, (hipStream_t)stream);
+    ngs_launch_adam_activated((hipStream_t)stream, P, raw, grad, exp_avg, exp_avg_sq, activated, lr, beta1, beta2, eps,
+                              step, grad_scale, dL_dmean2D, radii, xyz_gradient_accum, denom, max_radii2D);
+    prof_end(ps, ST_ADAM_ACTIVATED, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("stage Adam (activated groups)", hipGetErrorString(e));
     return 0;
 }
 

@@ -167,6 +167,19 @@ void ngs_launch_masked_color(hipStream_t s, int P, const uint8_t* clamped, const
 void ngs_launch_sh_from_views(hipStream_t s, int P, int D, int M, int V, const float* means, const float* campos,
                               long long campos_stride, const float* colors, long long colors_stride, float* dL_dsh);
 
+// train_ops.hip: fused L1 + SSIM image loss (value and gradient) and fused Adam + parameter activations.
+size_t ngs_loss_workspace_floats(int W, int H);
+void ngs_launch_l1_ssim(hipStream_t s, int W, int H, float lambda_dssim, const float* img, const float* gt,
+                        float* workspace, float* loss_terms, float* dL_dimg);
+void ngs_launch_adam_flat(hipStream_t s, long long n, float* param, const float* grad, float* exp_avg,
+                          float* exp_avg_sq, double lr_head, double lr_tail, int period, int head, double beta1,
+                          double beta2, double eps, int step, float grad_scale);
+void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const float* const grad[3],
+                               float* const exp_avg[3], float* const exp_avg_sq[3], float* const activated[3],
+                               const double lr[3], double beta1, double beta2, double eps, int step,
+                               float grad_scale, const float* dL_dmean2D, const int* radii, float* grad_accum,
+                               float* denom, int* max_radii);
+
 #ifdef __HIPCC__
 // ---------------------------------------------------------------------------
 // Device math shared by preprocess forward and backward.  Matrices are stored

@@ -1,0 +1,401 @@
+// The two per-iteration costs next to the rasterizer in the reference's training loop, as fused kernels:
+//
+//  * the image loss  (1 - lambda) * L1 + lambda * (1 - SSIM)  of train.py:90-92 with utils/loss_utils.py:17-63
+//    (11x11 Gaussian window, sigma 1.5, zero padding, per channel), forward value AND its gradient wrt the rendered
+//    image in two passes over the image, instead of five depthwise convolutions plus their autograd graph;
+//  * the optimiser step of scene/gaussian_model.py:257-283 (torch.optim.Adam, eps 1e-15, one learning rate per
+//    parameter group) fused with the parameter activations of gaussian_model.py:113-141 (sigmoid, exp, normalise) and
+//    their backward: the kernels take the gradients the rasterizer produces (wrt the ACTIVATED values), update the raw
+//    parameters and write the activated values the next forward pass reads.
+//
+// Everything here streams through HBM once; there is no reuse to exploit beyond the LDS tiles of the blur.
+#include "ngs_common.h"
+
+#define SSIM_RADIUS 5
+#define SSIM_TAPS (2 * SSIM_RADIUS + 1)
+#define SSIM_TILE 16
+#define SSIM_EXT (SSIM_TILE + 2 * SSIM_RADIUS)  // 26: tile plus halo
+#define SSIM_C1 (0.01f * 0.01f)
+#define SSIM_C2 (0.03f * 0.03f)
+
+struct SsimWindow {
+    float w[SSIM_TAPS];  // normalised 1-D Gaussian; the reference's 2-D window is its outer product
+};
+
+// Loads the SSIM_EXT x SSIM_EXT neighbourhood of tile (tx, ty) of one image plane into LDS, zeros outside the image
+// (the reference pads its convolutions with zeros).
+__device__ __forceinline__ void load_halo_tile(const float* __restrict__ plane, int W, int H, int tx, int ty,
+                                               float (*dst)[SSIM_EXT + 1], int tid)
+{
+    for (int i = tid; i < SSIM_EXT * SSIM_EXT; i += NGS_TILE_PIX) {
+        const int r = i / SSIM_EXT, c = i - r * SSIM_EXT;
+        const int gx = tx * SSIM_TILE + c - SSIM_RADIUS, gy = ty * SSIM_TILE + r - SSIM_RADIUS;
+        dst[r][c] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? plane[(size_t)gy * W + gx] : 0.0f;
+    }
+}
+
+// Pass 1: SSIM map, L1 term and the three per-pixel partial derivatives of the SSIM value wrt the blurred maps
+// mu1 = w*x, E1 = w*x^2, E12 = w*x*y (x the rendered image, y the ground truth).
+__global__ __launch_bounds__(NGS_TILE_PIX) void ssim_l1_forward_kernel(
+    int W, int H, SsimWindow win, const float* __restrict__ img, const float* __restrict__ gt,
+    float* __restrict__ d_mu1, float* __restrict__ d_e1, float* __restrict__ d_e12, float* __restrict__ partial_sums)
+{
+    __shared__ float sx[SSIM_EXT][SSIM_EXT + 1], sy[SSIM_EXT][SSIM_EXT + 1];
+    __shared__ float hb[5][SSIM_EXT][SSIM_TILE];
+    __shared__ float red[2][NGS_TILE_PIX / 64];
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + SSIM_TILE - 1) / SSIM_TILE;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, ch = blockIdx.y;
+    const size_t plane = (size_t)W * H;
+    load_halo_tile(img + ch * plane, W, H, tx, ty, sx, tid);
+    load_halo_tile(gt + ch * plane, W, H, tx, ty, sy, tid);
+    __syncthreads();
+    // horizontal blur of x, y, x^2, y^2, xy for every row of the halo tile
+    for (int i = tid; i < SSIM_EXT * SSIM_TILE; i += NGS_TILE_PIX) {
+        const int r = i / SSIM_TILE, c = i - r * SSIM_TILE;
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+        for (int k = 0; k < SSIM_TAPS; k++) {
+            const float x = sx[r][c + k], y = sy[r][c + k], w = win.w[k];
+            a0 += w * x;
+            a1 += w * y;
+            a2 += w * (x * x);
+            a3 += w * (y * y);
+            a4 += w * (x * y);
+        }
+        hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2; hb[3][r][c] = a3; hb[4][r][c] = a4;
+    }
+    __syncthreads();
+    const int lx = tid & (SSIM_TILE - 1), ly = tid / SSIM_TILE;
+    const int gx = tx * SSIM_TILE + lx, gy = ty * SSIM_TILE + ly;
+    float s_val = 0.0f, l1_val = 0.0f;
+    if (gx < W && gy < H) {
+        float mu1 = 0, mu2 = 0, e1 = 0, e2 = 0, e12 = 0;
+#pragma unroll
+        for (int k = 0; k < SSIM_TAPS; k++) {
+            const float w = win.w[k];
+            mu1 += w * hb[0][ly + k][lx];
+            mu2 += w * hb[1][ly + k][lx];
+            e1 += w * hb[2][ly + k][lx];
+            e2 += w * hb[3][ly + k][lx];
+            e12 += w * hb[4][ly + k][lx];
+        }
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float sigma1 = e1 - mu1_sq, sigma2 = e2 - mu2_sq, sigma12 = e12 - mu12;
+        const float n1 = 2.0f * mu12 + SSIM_C1, n2 = 2.0f * sigma12 + SSIM_C2;
+        const float q1 = mu1_sq + mu2_sq + SSIM_C1, q2 = sigma1 + sigma2 + SSIM_C2;
+        const float inv = 1.0f / (q1 * q2);
+        s_val = (n1 * n2) * inv;
+        // d/d(mu1) with E1, E12 fixed: n1' = 2 mu2, n2' = -2 mu2, q1' = 2 mu1, q2' = -2 mu1
+        const float dnum = 2.0f * mu2 * (n2 - n1);
+        const float dden = 2.0f * mu1 * (q2 - q1);
+        const size_t p = ch * plane + (size_t)gy * W + gx;
+        d_mu1[p] = (dnum - s_val * dden) * inv;
+        d_e1[p] = -s_val / q2;
+        d_e12[p] = 2.0f * n1 * inv;
+        l1_val = fabsf(sx[ly + SSIM_RADIUS][lx + SSIM_RADIUS] - sy[ly + SSIM_RADIUS][lx + SSIM_RADIUS]);
+    }
+    // block sums, in a fixed order (the final reduction is a single block as well: the loss value is deterministic)
+    const float ws = wave_sum_lane63(s_val), wl = wave_sum_lane63(l1_val);
+    if ((tid & 63) == 63) {
+        red[0][tid >> 6] = ws;
+        red[1][tid >> 6] = wl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partial_sums[2 * b] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial_sums[2 * b + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// loss_terms = {L1 mean, SSIM mean, (1 - lambda) * L1 + lambda * (1 - SSIM)}
+__global__ __launch_bounds__(NGS_TILE_PIX) void loss_reduce_kernel(int nblocks, const float* __restrict__ partial_sums,
+                                                                 float inv_count, float lambda_dssim,
+                                                                 float* __restrict__ loss_terms)
+{
+    __shared__ double red[2][NGS_TILE_PIX];
+    double s = 0.0, l = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += NGS_TILE_PIX) {
+        s += (double)partial_sums[2 * i];
+        l += (double)partial_sums[2 * i + 1];
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = l;
+    __syncthreads();
+    for (int o = NGS_TILE_PIX / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float ssim = (float)(red[0][0] * (double)inv_count), l1 = (float)(red[1][0] * (double)inv_count);
+        loss_terms[0] = l1;
+        loss_terms[1] = ssim;
+        loss_terms[2] = (1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ssim);
+    }
+}
+
+// Pass 2: dLoss/dx = c_l1 * sign(x - y) - c_ssim * (w*d_mu1 + 2 x (w*d_e1) + y (w*d_e12)), the transposed
+// convolutions being the same symmetric blur with zeros outside the image.
+__global__ __launch_bounds__(NGS_TILE_PIX) void ssim_l1_backward_kernel(
+    int W, int H, SsimWindow win, const float* __restrict__ img, const float* __restrict__ gt,
+    const float* __restrict__ d_mu1, const float* __restrict__ d_e1, const float* __restrict__ d_e12, float c_l1,
+    float c_ssim, float* __restrict__ dL_dimg)
+{
+    __shared__ float sp[3][SSIM_EXT][SSIM_EXT + 1];
+    __shared__ float hb[3][SSIM_EXT][SSIM_TILE];
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + SSIM_TILE - 1) / SSIM_TILE;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, ch = blockIdx.y;
+    const size_t plane = (size_t)W * H;
+    load_halo_tile(d_mu1 + ch * plane, W, H, tx, ty, sp[0], tid);
+    load_halo_tile(d_e1 + ch * plane, W, H, tx, ty, sp[1], tid);
+    load_halo_tile(d_e12 + ch * plane, W, H, tx, ty, sp[2], tid);
+    __syncthreads();
+    for (int i = tid; i < SSIM_EXT * SSIM_TILE; i += NGS_TILE_PIX) {
+        const int r = i / SSIM_TILE, c = i - r * SSIM_TILE;
+        float a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int k = 0; k < SSIM_TAPS; k++) {
+            const float w = win.w[k];
+            a0 += w * sp[0][r][c + k];
+            a1 += w * sp[1][r][c + k];
+            a2 += w * sp[2][r][c + k];
+        }
+        hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2;
+    }
+    __syncthreads();
+    const int lx = tid & (SSIM_TILE - 1), ly = tid / SSIM_TILE;
+    const int gx = tx * SSIM_TILE + lx, gy = ty * SSIM_TILE + ly;
+    if (gx < W && gy < H) {
+        float b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+        for (int k = 0; k < SSIM_TAPS; k++) {
+            const float w = win.w[k];
+            b0 += w * hb[0][ly + k][lx];
+            b1 += w * hb[1][ly + k][lx];
+            b2 += w * hb[2][ly + k][lx];
+        }
+        const size_t p = ch * plane + (size_t)gy * W + gx;
+        const float x = img[p], y = gt[p], d = x - y;
+        const float sgn = d > 0.0f ? 1.0f : d < 0.0f ? -1.0f : 0.0f;
+        dL_dimg[p] = c_l1 * sgn - c_ssim * (b0 + 2.0f * x * b1 + y * b2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adam.  Operation order of torch.optim.Adam's single-tensor path: exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v +
+// (1-b2)*g*g; denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom.
+// ---------------------------------------------------------------------------------------------------------------
+// The scalars are formed on the host in double and rounded to float once, as torch does with its Python floats:
+// one_minus_beta1 = float(1 - beta1), one_minus_beta2 = float(1 - beta2), bc2_sqrt = float(sqrt(1 - beta2^t)), and a
+// group's `step` below is float(lr / (1 - beta1^t)).
+struct AdamConst {
+    float one_minus_beta1, beta2, one_minus_beta2, eps, bc2_sqrt, grad_scale;
+};
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float step, const AdamConst& k)
+{
+    m = m + k.one_minus_beta1 * (g - m);
+    v = v * k.beta2 + k.one_minus_beta2 * g * g;
+    const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+    return p - step * (m / denom);
+}
+
+// Flat tensor whose activation is the identity (positions, SH coefficients).  Elements whose index modulo `period`
+// is below `head` use lr_head, the others lr_tail (SH rows [P][M][3]: the DC coefficient and the higher bands are
+// separate parameter groups in the reference, gaussian_model.py:262-263).
+__global__ __launch_bounds__(256) void adam_flat_kernel(long long n, float* __restrict__ param,
+                                                        const float* __restrict__ grad, float* __restrict__ exp_avg,
+                                                        float* __restrict__ exp_avg_sq, float step_head, float step_tail,
+                                                        int period, int head, AdamConst k)
+{
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 4 <= n) {
+        float4 p = *(const float4*)(param + i4), g = *(const float4*)(grad + i4);
+        float4 m = *(const float4*)(exp_avg + i4), v = *(const float4*)(exp_avg_sq + i4);
+        const int r = (int)(i4 % period);
+        p.x = adam_update(p.x, g.x * k.grad_scale, m.x, v.x, (r + 0) % period < head ? step_head : step_tail, k);
+        p.y = adam_update(p.y, g.y * k.grad_scale, m.y, v.y, (r + 1) % period < head ? step_head : step_tail, k);
+        p.z = adam_update(p.z, g.z * k.grad_scale, m.z, v.z, (r + 2) % period < head ? step_head : step_tail, k);
+        p.w = adam_update(p.w, g.w * k.grad_scale, m.w, v.w, (r + 3) % period < head ? step_head : step_tail, k);
+        *(float4*)(param + i4) = p;
+        *(float4*)(exp_avg + i4) = m;
+        *(float4*)(exp_avg_sq + i4) = v;
+    } else {
+        for (long long i = i4; i < n; i++) {
+            float m = exp_avg[i], v = exp_avg_sq[i];
+            param[i] = adam_update(param[i], grad[i] * k.grad_scale, m, v, (int)(i % period) < head ? step_head : step_tail, k);
+            exp_avg[i] = m;
+            exp_avg_sq[i] = v;
+        }
+    }
+}
+
+struct ActivatedGroup {
+    float* raw;        // raw parameter, updated in place
+    const float* grad; // gradient wrt the ACTIVATED value (what the rasterizer's backward returns)
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* activated;  // activated value for the next forward pass, written here
+    float step;        // float(lr / (1 - beta1^t))
+};
+
+// One lane per Gaussian: opacity (sigmoid), scale (exp) and rotation (normalise), each with the backward of its
+// activation, Adam, and the new activated value; plus the densification statistics of train.py:113-116 /
+// gaussian_model.py:550-552 when their arrays are given.
+__global__ __launch_bounds__(256) void adam_activated_kernel(int P, ActivatedGroup op, ActivatedGroup sc,
+                                                             ActivatedGroup ro, AdamConst k,
+                                                             const float* __restrict__ dL_dmean2D,
+                                                             const int* __restrict__ radii,
+                                                             float* __restrict__ grad_accum,
+                                                             float* __restrict__ denom, int* __restrict__ max_radii)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const size_t i = (size_t)idx;
+    {   // opacity = sigmoid(raw): d raw = d act * act * (1 - act)
+        const float raw = op.raw[i];
+        const float act = 1.0f / (1.0f + expf(-raw));
+        const float g = (op.grad[i] * k.grad_scale) * ((1.0f - act) * act);
+        float m = op.exp_avg[i], v = op.exp_avg_sq[i];
+        const float nr = adam_update(raw, g, m, v, op.step, k);
+        op.raw[i] = nr;
+        op.exp_avg[i] = m;
+        op.exp_avg_sq[i] = v;
+        op.activated[i] = 1.0f / (1.0f + expf(-nr));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {  // scale = exp(raw): d raw = d act * act
+        const size_t j = 3 * i + c;
+        const float raw = sc.raw[j];
+        const float g = (sc.grad[j] * k.grad_scale) * expf(raw);
+        float m = sc.exp_avg[j], v = sc.exp_avg_sq[j];
+        const float nr = adam_update(raw, g, m, v, sc.step, k);
+        sc.raw[j] = nr;
+        sc.exp_avg[j] = m;
+        sc.exp_avg_sq[j] = v;
+        sc.activated[j] = expf(nr);
+    }
+    {   // rotation = raw / max(|raw|, 1e-12): d raw = (d act - act (act . d act)) / |raw|
+        const float4 raw = ((const float4*)ro.raw)[i];
+        float4 g = ((const float4*)ro.grad)[i];
+        g.x *= k.grad_scale; g.y *= k.grad_scale; g.z *= k.grad_scale; g.w *= k.grad_scale;
+        const float len = fmaxf(sqrtf(raw.x * raw.x + raw.y * raw.y + raw.z * raw.z + raw.w * raw.w), 1e-12f);
+        const float4 a = make_float4(raw.x / len, raw.y / len, raw.z / len, raw.w / len);
+        const float dot = a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+        const float4 gr = make_float4((g.x - a.x * dot) / len, (g.y - a.y * dot) / len, (g.z - a.z * dot) / len,
+                                      (g.w - a.w * dot) / len);
+        float4 m = ((const float4*)ro.exp_avg)[i], v = ((const float4*)ro.exp_avg_sq)[i];
+        float4 nr;
+        nr.x = adam_update(raw.x, gr.x, m.x, v.x, ro.step, k);
+        nr.y = adam_update(raw.y, gr.y, m.y, v.y, ro.step, k);
+        nr.z = adam_update(raw.z, gr.z, m.z, v.z, ro.step, k);
+        nr.w = adam_update(raw.w, gr.w, m.w, v.w, ro.step, k);
+        ((float4*)ro.raw)[i] = nr;
+        ((float4*)ro.exp_avg)[i] = m;
+        ((float4*)ro.exp_avg_sq)[i] = v;
+        const float nl = fmaxf(sqrtf(nr.x * nr.x + nr.y * nr.y + nr.z * nr.z + nr.w * nr.w), 1e-12f);
+        ((float4*)ro.activated)[i] = make_float4(nr.x / nl, nr.y / nl, nr.z / nl, nr.w / nl);
+    }
+    if (grad_accum) {
+        const int r = radii[i];
+        if (r > 0) {
+            const float gx = dL_dmean2D[3 * i], gy = dL_dmean2D[3 * i + 1];
+            grad_accum[i] += sqrtf(gx * gx + gy * gy);
+            denom[i] += 1.0f;
+            max_radii[i] = max(max_radii[i], r);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host side.
+// ---------------------------------------------------------------------------------------------------------------
+static SsimWindow make_window()
+{
+    // utils/loss_utils.py:23-25: exp() in double, stored as float32, normalised in float32
+    SsimWindow w;
+    float sum = 0.0f;
+    for (int i = 0; i < SSIM_TAPS; i++) {
+        const double d = (double)(i - SSIM_RADIUS);
+        w.w[i] = (float)exp(-(d * d) / (2.0 * 1.5 * 1.5));
+        sum += w.w[i];
+    }
+    for (int i = 0; i < SSIM_TAPS; i++) w.w[i] /= sum;
+    return w;
+}
+
+size_t ngs_loss_workspace_floats(int W, int H)
+{
+    const size_t tiles = (size_t)((W + SSIM_TILE - 1) / SSIM_TILE) * ((H + SSIM_TILE - 1) / SSIM_TILE);
+    return 9 * (size_t)W * H + 2 * 3 * tiles;
+}
+
+void ngs_launch_l1_ssim(hipStream_t s, int W, int H, float lambda_dssim, const float* img, const float* gt,
+                        float* workspace, float* loss_terms, float* dL_dimg)
+{
+    const SsimWindow win = make_window();
+    const size_t n = 3 * (size_t)W * H;
+    float* d_mu1 = workspace;
+    float* d_e1 = workspace + n;
+    float* d_e12 = workspace + 2 * n;
+    float* partial = workspace + 3 * n;
+    const int tiles = ((W + SSIM_TILE - 1) / SSIM_TILE) * ((H + SSIM_TILE - 1) / SSIM_TILE);
+    hipLaunchKernelGGL(ssim_l1_forward_kernel, dim3(tiles, 3), dim3(NGS_TILE_PIX), 0, s, W, H, win, img, gt, d_mu1,
+                       d_e1, d_e12, partial);
+    const float inv_count = (float)(1.0 / (double)n);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(NGS_TILE_PIX), 0, s, tiles * 3, partial, inv_count,
+                       lambda_dssim, loss_terms);
+    hipLaunchKernelGGL(ssim_l1_backward_kernel, dim3(tiles, 3), dim3(NGS_TILE_PIX), 0, s, W, H, win, img, gt, d_mu1,
+                       d_e1, d_e12, (1.0f - lambda_dssim) * inv_count, lambda_dssim * inv_count, dL_dimg);
+}
+
+static AdamConst adam_const(double beta1, double beta2, double eps, int step, float grad_scale)
+{
+    AdamConst k;
+    k.one_minus_beta1 = (float)(1.0 - beta1);
+    k.beta2 = (float)beta2;
+    k.one_minus_beta2 = (float)(1.0 - beta2);
+    k.eps = (float)eps;
+    k.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    k.grad_scale = grad_scale;
+    return k;
+}
+
+static float adam_step_size(double lr, double beta1, int step) { return (float)(lr / (1.0 - pow(beta1, (double)step))); }
+
+void ngs_launch_adam_flat(hipStream_t s, long long n, float* param, const float* grad, float* exp_avg,
+                          float* exp_avg_sq, double lr_head, double lr_tail, int period, int head, double beta1,
+                          double beta2, double eps, int step, float grad_scale)
+{
+    const long long quads = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, n, param, grad,
+                       exp_avg, exp_avg_sq, adam_step_size(lr_head, beta1, step), adam_step_size(lr_tail, beta1, step),
+                       period, head, adam_const(beta1, beta2, eps, step, grad_scale));
+}
+
+void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const float* const grad[3],
+                               float* const exp_avg[3], float* const exp_avg_sq[3], float* const activated[3],
+                               const double lr[3], double beta1, double beta2, double eps, int step,
+                               float grad_scale,
+                               const float* dL_dmean2D, const int* radii, float* grad_accum, float* denom,
+                               int* max_radii)
+{
+    ActivatedGroup g[3];
+    for (int i = 0; i < 3; i++) {
+        g[i].raw = raw[i];
+        g[i].grad = grad[i];
+        g[i].exp_avg = exp_avg[i];
+        g[i].exp_avg_sq = exp_avg_sq[i];
+        g[i].activated = activated[i];
+        g[i].step = adam_step_size(lr[i], beta1, step);
+    }
+    hipLaunchKernelGGL(adam_activated_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g[0], g[1], g[2],
+                       adam_const(beta1, beta2, eps, step, grad_scale), dL_dmean2D, radii, grad_accum, denom,
+                       max_radii);
+}

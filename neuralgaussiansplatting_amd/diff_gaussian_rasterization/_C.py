@@ -38,6 +38,10 @@ def lib():
         L.ngs_state_layout.restype = ctypes.c_int
         L.ngs_masked_color_gradient.restype = ctypes.c_int
         L.ngs_sh_gradient_from_views.restype = ctypes.c_int
+        L.ngs_loss_workspace_bytes.restype = ctypes.c_size_t
+        L.ngs_l1_ssim_loss.restype = ctypes.c_int
+        L.ngs_adam_step.restype = ctypes.c_int
+        L.ngs_adam_step_activated.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -216,6 +220,87 @@ def sh_gradient_from_views(means3D, campos, dL_dcolor_views, degree, M, out=None
                 P, int(degree), int(M), V, _ptr(means3D), _ptr(campos), ctypes.c_longlong(cs),
                 _ptr(dL_dcolor_views), ctypes.c_longlong(vs), _ptr(out), _stream(dev)))
     return out.view(P, M, 3)
+
+
+def l1_ssim_loss(image, gt_image, lambda_dssim=0.2, workspace=None, out=None):
+    """Fused image loss of the training step: ``(1 - lambda) * L1 + lambda * (1 - SSIM)`` (train.py:90-92 with
+    utils/loss_utils.py:17-63) and its gradient wrt ``image``, both [3,H,W].
+    -> (loss_terms, dL_dimage); loss_terms is a device tensor {L1 mean, SSIM mean, loss} (no host sync here).
+    ``workspace`` (float32, at least ``loss_workspace_floats(W, H)`` elements) and ``out`` avoid allocations."""
+    _require_gpu(image)
+    dev = image.device
+    if image.dim() != 3 or image.size(0) != NUM_CHANNELS or gt_image.shape != image.shape:
+        raise RuntimeError("image and gt_image must both be [3, H, W]")
+    image, gt_image = _f32(image, dev), _f32(gt_image, dev)
+    H, W = image.size(1), image.size(2)
+    need = loss_workspace_floats(W, H)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.float32, device=dev)
+    elif workspace.numel() < need or workspace.dtype != torch.float32 or workspace.device != dev:
+        raise RuntimeError("workspace must hold at least %d float32 elements on %s" % (need, dev))
+    dL = torch.empty_like(image) if out is None else out
+    terms = torch.empty(3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().ngs_l1_ssim_loss(W, H, ctypes.c_float(lambda_dssim), _ptr(image), _ptr(gt_image),
+                                      _ptr(workspace), _ptr(terms), _ptr(dL), _stream(dev)))
+    return terms, dL
+
+
+def loss_workspace_floats(W, H):
+    return lib().ngs_loss_workspace_bytes(int(W), int(H)) // 4
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, lr_tail=None, period=1, head=1, betas=(0.9, 0.999),
+              eps=1e-15, grad_scale=1.0):
+    """torch.optim.Adam's update of one tensor whose activation is the identity, in place (the reference's optimiser,
+    scene/gaussian_model.py:275).  Elements whose flat index modulo ``period`` is below ``head`` use ``lr``, the
+    others ``lr_tail``."""
+    _require_gpu(param)
+    dev = param.device
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != param.numel():
+            raise RuntimeError("Adam tensors must be contiguous float32 on %s with equal sizes" % dev)
+    with torch.cuda.device(dev):
+        _check(lib().ngs_adam_step(
+            ctypes.c_longlong(param.numel()), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+            ctypes.c_double(lr), ctypes.c_double(lr if lr_tail is None else lr_tail), int(period), int(head),
+            ctypes.c_double(betas[0]), ctypes.c_double(betas[1]), ctypes.c_double(eps), int(step),
+            ctypes.c_float(grad_scale), _stream(dev)))
+
+
+def adam_step_activated(raw, grad, exp_avg, exp_avg_sq, activated, lrs, step, betas=(0.9, 0.999), eps=1e-15,
+                        grad_scale=1.0, densify=None):
+    """Adam for (opacity, scaling, rotation): each argument is a 3-tuple of tensors in that order.  ``grad`` holds
+    the gradients wrt the ACTIVATED values; raw values and Adam state are updated in place and ``activated``
+    receives sigmoid / exp / normalise of the new raw values.  ``densify`` = (dL_dmean2D [P,3], radii [P] int32,
+    xyz_gradient_accum [P,1], denom [P,1], max_radii2D [P] int32) also updates the densification statistics
+    (gaussian_model.py:550-552, train.py:115)."""
+    _require_gpu(raw[0])
+    dev = raw[0].device
+    P = raw[0].numel()
+    widths = (1, 3, 4)
+    for group in (raw, grad, exp_avg, exp_avg_sq, activated):
+        for t, w in zip(group, widths):
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != P * w:
+                raise RuntimeError("opacity/scaling/rotation tensors must be contiguous float32 [P,1], [P,3], [P,4] "
+                                   "on %s" % dev)
+    arr = lambda group: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in group])
+    null = ctypes.c_void_p(0)
+    d = [null] * 5
+    if densify is not None:
+        g2d, radii, accum, denom, max_radii = densify
+        if (g2d.dtype != torch.float32 or radii.dtype != torch.int32 or accum.dtype != torch.float32 or
+                denom.dtype != torch.float32 or max_radii.dtype != torch.int32 or g2d.numel() != 3 * P or
+                any(t.numel() != P for t in (radii, accum, denom, max_radii)) or
+                any(t.device != dev or not t.is_contiguous() for t in densify)):
+            raise RuntimeError("densification statistics: float32 [P,3], int32 [P], float32 [P,1] x2, int32 [P] on %s"
+                               % dev)
+        d = [_ptr(t) for t in densify]
+    with torch.cuda.device(dev):
+        _check(lib().ngs_adam_step_activated(
+            P, arr(raw), arr(grad), arr(exp_avg), arr(exp_avg_sq), arr(activated),
+            (ctypes.c_double * 3)(*[float(x) for x in lrs]), ctypes.c_double(betas[0]), ctypes.c_double(betas[1]),
+            ctypes.c_double(eps), int(step), ctypes.c_float(grad_scale), d[0], d[1], d[2], d[3], d[4], _stream(dev)))
 
 
 def profile_enable(on=True):

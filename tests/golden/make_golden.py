@@ -8,7 +8,9 @@ CUDA sources cannot be built here, so these fixtures pin what its Python can
 pin: SH -> RGB (utils/sh_utils.py:57-112, the function behind the
 ``convert_SHs_python`` switch, gaussian_renderer/__init__.py:74-79), the
 camera matrices (utils/graphics_utils.py:38-71 combined as in
-scene/cameras.py:54-57) and the training loss terms (utils/loss_utils.py:17-63).
+scene/cameras.py:54-57), the training loss terms (utils/loss_utils.py:17-63), the
+combined loss of train.py:90-92 with its gradient wrt the image, and the
+position learning-rate schedule (utils/general_utils.py:29-61).
 Only inputs and outputs are stored.
 """
 import math
@@ -72,8 +74,35 @@ def loss_fixture():
              l1=np.float64(l1_loss(a, b).item()), ssim=np.float64(ssim(a, b).item()))
 
 
+def train_loss_fixture():
+    """Loss of train.py:90-92 and its gradient wrt the rendered image, through the reference's own functions."""
+    g = torch.Generator().manual_seed(11)
+    a = torch.rand(3, 45, 70, generator=g, requires_grad=True)  # not a multiple of the 16-pixel tiles
+    b = (a.detach() + 0.15 * torch.randn(3, 45, 70, generator=g)).clamp(0, 1)
+    b[:, 10:20, 30:50] = a.detach()[:, 10:20, 30:50]  # a region of exact agreement: sign(0) = 0 in the L1 term
+    lam = 0.2
+    ll1 = l1_loss(a, b)
+    s = ssim(a, b)
+    loss = (1.0 - lam) * ll1 + lam * (1.0 - s)
+    loss.backward()
+    np.savez(os.path.join(HERE, "train_loss.npz"), img=a.detach().numpy(), gt=b.numpy(), lambda_dssim=np.float64(lam),
+             l1=np.float64(ll1.item()), ssim=np.float64(s.item()), loss=np.float64(loss.item()), grad=a.grad.numpy())
+
+
+def lr_fixture():
+    """Position learning-rate schedule (utils/general_utils.py:29-61) with the defaults of arguments/__init__.py:74-77."""
+    from utils.general_utils import get_expon_lr_func
+    steps = np.array([0, 1, 2, 10, 100, 999, 1000, 7000, 15000, 29999, 30000, 40000], dtype=np.int64)
+    f = get_expon_lr_func(lr_init=0.00016, lr_final=0.0000016, lr_delay_mult=0.01, max_steps=30_000)
+    f2 = get_expon_lr_func(lr_init=0.01, lr_final=0.0001, lr_delay_steps=500, lr_delay_mult=0.05, max_steps=5000)
+    np.savez(os.path.join(HERE, "expon_lr.npz"), steps=steps, default=np.array([f(int(s)) for s in steps]),
+             delayed=np.array([f2(int(s)) for s in steps]))
+
+
 if __name__ == "__main__":
     sh_fixture()
     camera_fixture()
     loss_fixture()
+    train_loss_fixture()
+    lr_fixture()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
