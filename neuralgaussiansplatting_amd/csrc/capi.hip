@@ -449,6 +449,7 @@ extern "C" int ngs_l1_ssim_loss(int width, int height, float lambda_dssim, const
     if (width <= 0 || height <= 0) return fail("ngs_l1_ssim_loss", "bad sizes");
     if (!image || !gt_image || !workspace || !loss_terms || !dL_dimage)
         return fail("ngs_l1_ssim_loss", "missing required pointer");
+    if ((uintptr_t)workspace % 8 != 0) return fail("ngs_l1_ssim_loss", "workspace must be 8-byte aligned");
     const int ps = prof_acquire();
     prof_begin(ps, ST_LOSS, (hipStream_t)stream);
     ngs_launch_l1_ssim((hipStream_t)stream, width, height, lambda_dssim, image, gt_image, workspace, loss_terms,

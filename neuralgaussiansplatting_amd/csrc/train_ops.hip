@@ -40,6 +40,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void ssim_l1_forward_kernel(
     int W, int H, SsimWindow win, const float* __restrict__ img, const float* __restrict__ gt,
     float* __restrict__ d_mu1, float* __restrict__ d_e1, float* __restrict__ d_e12, float* __restrict__ partial_sums)
 {
+#pragma clang fp contract(fast)  // the blurs are FMA chains; nothing here has to match another evaluation bit for bit
     __shared__ float sx[SSIM_EXT][SSIM_EXT + 1], sy[SSIM_EXT][SSIM_EXT + 1];
     __shared__ float hb[5][SSIM_EXT][SSIM_TILE];
     __shared__ float red[2][NGS_TILE_PIX / 64];
@@ -110,20 +111,23 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void ssim_l1_forward_kernel(
 }
 
 // loss_terms = {L1 mean, SSIM mean, (1 - lambda) * L1 + lambda * (1 - SSIM)}
-__global__ __launch_bounds__(NGS_TILE_PIX) void loss_reduce_kernel(int nblocks, const float* __restrict__ partial_sums,
-                                                                 float inv_count, float lambda_dssim,
-                                                                 float* __restrict__ loss_terms)
+#define LOSS_REDUCE_THREADS 1024
+__global__ __launch_bounds__(LOSS_REDUCE_THREADS) void loss_reduce_kernel(int nblocks,
+                                                                        const float* __restrict__ partial_sums,
+                                                                        float inv_count, float lambda_dssim,
+                                                                        float* __restrict__ loss_terms)
 {
-    __shared__ double red[2][NGS_TILE_PIX];
+    __shared__ double red[2][LOSS_REDUCE_THREADS];
     double s = 0.0, l = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += NGS_TILE_PIX) {
-        s += (double)partial_sums[2 * i];
-        l += (double)partial_sums[2 * i + 1];
+    for (int i = threadIdx.x; i < nblocks; i += LOSS_REDUCE_THREADS) {
+        const float2 v = ((const float2*)partial_sums)[i];
+        s += (double)v.x;
+        l += (double)v.y;
     }
     red[0][threadIdx.x] = s;
     red[1][threadIdx.x] = l;
     __syncthreads();
-    for (int o = NGS_TILE_PIX / 2; o > 0; o >>= 1) {
+    for (int o = LOSS_REDUCE_THREADS / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
             red[0][threadIdx.x] += red[0][threadIdx.x + o];
             red[1][threadIdx.x] += red[1][threadIdx.x + o];
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void ssim_l1_backward_kernel(
     const float* __restrict__ d_mu1, const float* __restrict__ d_e1, const float* __restrict__ d_e12, float c_l1,
     float c_ssim, float* __restrict__ dL_dimg)
 {
+#pragma clang fp contract(fast)
     __shared__ float sp[3][SSIM_EXT][SSIM_EXT + 1];
     __shared__ float hb[3][SSIM_EXT][SSIM_TILE];
     const int tid = threadIdx.x;
@@ -210,28 +215,38 @@ __device__ __forceinline__ float adam_update(float p, float g, float& m, float& 
 // separate parameter groups in the reference, gaussian_model.py:262-263).
 __global__ __launch_bounds__(256) void adam_flat_kernel(long long n, float* __restrict__ param,
                                                         const float* __restrict__ grad, float* __restrict__ exp_avg,
-                                                        float* __restrict__ exp_avg_sq, float step_head, float step_tail,
-                                                        int period, int head, AdamConst k)
+                                                        float* __restrict__ exp_avg_sq, float step_head,
+                                                        float step_tail, int period, int head, AdamConst k)
 {
-    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= n) return;
-    if (i4 + 4 <= n) {
-        float4 p = *(const float4*)(param + i4), g = *(const float4*)(grad + i4);
-        float4 m = *(const float4*)(exp_avg + i4), v = *(const float4*)(exp_avg_sq + i4);
-        const int r = (int)(i4 % period);
-        p.x = adam_update(p.x, g.x * k.grad_scale, m.x, v.x, (r + 0) % period < head ? step_head : step_tail, k);
-        p.y = adam_update(p.y, g.y * k.grad_scale, m.y, v.y, (r + 1) % period < head ? step_head : step_tail, k);
-        p.z = adam_update(p.z, g.z * k.grad_scale, m.z, v.z, (r + 2) % period < head ? step_head : step_tail, k);
-        p.w = adam_update(p.w, g.w * k.grad_scale, m.w, v.w, (r + 3) % period < head ? step_head : step_tail, k);
-        *(float4*)(param + i4) = p;
-        *(float4*)(exp_avg + i4) = m;
-        *(float4*)(exp_avg_sq + i4) = v;
-    } else {
-        for (long long i = i4; i < n; i++) {
-            float m = exp_avg[i], v = exp_avg_sq[i];
-            param[i] = adam_update(param[i], grad[i] * k.grad_scale, m, v, (int)(i % period) < head ? step_head : step_tail, k);
-            exp_avg[i] = m;
-            exp_avg_sq[i] = v;
+    // Each thread owns two float4 groups a whole workgroup-stride apart, so all eight 16-byte loads of a lane are
+    // in flight together and every wave instruction still covers 1 KiB of contiguous memory.
+    const long long base = (long long)blockIdx.x * 2048 + threadIdx.x * 4;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const long long i4 = base + half * 1024;
+        if (i4 >= n) return;
+        // position inside the period: 32-bit arithmetic whenever the index fits (a 64-bit modulo is ~100 instructions)
+        unsigned r = i4 < 0x7fffffffLL ? (unsigned)i4 % (unsigned)period : (unsigned)(i4 % period);
+        if (i4 + 4 <= n) {
+            float4 p = *(const float4*)(param + i4), g = *(const float4*)(grad + i4);
+            float4 m = *(const float4*)(exp_avg + i4), v = *(const float4*)(exp_avg_sq + i4);
+            float* pe = &p.x; float* ge = &g.x; float* me = &m.x; float* ve = &v.x;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                pe[e] = adam_update(pe[e], ge[e] * k.grad_scale, me[e], ve[e], (int)r < head ? step_head : step_tail, k);
+                r = r + 1 == (unsigned)period ? 0u : r + 1;
+            }
+            *(float4*)(param + i4) = p;
+            *(float4*)(exp_avg + i4) = m;
+            *(float4*)(exp_avg_sq + i4) = v;
+        } else {
+            for (long long i = i4; i < n; i++) {
+                float m = exp_avg[i], v = exp_avg_sq[i];
+                param[i] = adam_update(param[i], grad[i] * k.grad_scale, m, v, (int)r < head ? step_head : step_tail, k);
+                exp_avg[i] = m;
+                exp_avg_sq[i] = v;
+                r = r + 1 == (unsigned)period ? 0u : r + 1;
+            }
         }
     }
 }
@@ -333,7 +348,7 @@ static SsimWindow make_window()
 size_t ngs_loss_workspace_floats(int W, int H)
 {
     const size_t tiles = (size_t)((W + SSIM_TILE - 1) / SSIM_TILE) * ((H + SSIM_TILE - 1) / SSIM_TILE);
-    return 9 * (size_t)W * H + 2 * 3 * tiles;
+    return 9 * (size_t)W * H + 2 + 2 * 3 * tiles;  // +2: the block sums start on an 8-byte boundary
 }
 
 void ngs_launch_l1_ssim(hipStream_t s, int W, int H, float lambda_dssim, const float* img, const float* gt,
@@ -344,12 +359,12 @@ void ngs_launch_l1_ssim(hipStream_t s, int W, int H, float lambda_dssim, const f
     float* d_mu1 = workspace;
     float* d_e1 = workspace + n;
     float* d_e12 = workspace + 2 * n;
-    float* partial = workspace + 3 * n;
+    float* partial = workspace + ((3 * n + 1) & ~(size_t)1);  // read back as float2
     const int tiles = ((W + SSIM_TILE - 1) / SSIM_TILE) * ((H + SSIM_TILE - 1) / SSIM_TILE);
     hipLaunchKernelGGL(ssim_l1_forward_kernel, dim3(tiles, 3), dim3(NGS_TILE_PIX), 0, s, W, H, win, img, gt, d_mu1,
                        d_e1, d_e12, partial);
     const float inv_count = (float)(1.0 / (double)n);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(NGS_TILE_PIX), 0, s, tiles * 3, partial, inv_count,
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(LOSS_REDUCE_THREADS), 0, s, tiles * 3, partial, inv_count,
                        lambda_dssim, loss_terms);
     hipLaunchKernelGGL(ssim_l1_backward_kernel, dim3(tiles, 3), dim3(NGS_TILE_PIX), 0, s, W, H, win, img, gt, d_mu1,
                        d_e1, d_e12, (1.0f - lambda_dssim) * inv_count, lambda_dssim * inv_count, dL_dimg);
@@ -373,8 +388,7 @@ void ngs_launch_adam_flat(hipStream_t s, long long n, float* param, const float*
                           float* exp_avg_sq, double lr_head, double lr_tail, int period, int head, double beta1,
                           double beta2, double eps, int step, float grad_scale)
 {
-    const long long quads = (n + 3) / 4;
-    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, n, param, grad,
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, n, param, grad,
                        exp_avg, exp_avg_sq, adam_step_size(lr_head, beta1, step), adam_step_size(lr_tail, beta1, step),
                        period, head, adam_const(beta1, beta2, eps, step, grad_scale));
 }

@@ -78,13 +78,25 @@ class _Growable:
     """A byte tensor the library grows through its allocator callback
     (the reference's resizeFunctional, rasterize_points.cu:27-33)."""
 
-    def __init__(self, device):
-        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+    def __init__(self, device, reserve=0):
+        """``reserve`` bytes are allocated up front, so that a request that fits costs no allocation: the library
+        asks for the binning buffer while the GPU is idle waiting for the host, where every microsecond shows."""
+        self.t = torch.empty(int(reserve), dtype=torch.uint8, device=device)
+        self.ptr = self.t.data_ptr() if reserve else 0
+        self.asked = 0
         self.cb = _ALLOC_FN(self._grow)
 
     def _grow(self, _ctx, nbytes):
-        self.t.resize_(int(nbytes))
-        return self.t.data_ptr()
+        self.asked = nbytes
+        if nbytes > self.t.numel():
+            self.t.resize_(int(nbytes))
+            self.ptr = self.t.data_ptr()
+        return self.ptr
+
+
+# Size the binning buffer had to have in the previous call with the same problem shape, per (device, P, W, H):
+# consecutive calls of a training or rendering loop need nearly the same amount.
+_binning_hint = {}
 
 
 def _stream(device):
@@ -103,7 +115,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     means3D, colors, opacity, scales, rotations, cov3D_precomp, sh = (
         _f32(x, dev) for x in (means3D, colors, opacity, scales, rotations, cov3D_precomp, sh))
     background, viewmatrix, projmatrix, campos = (_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
-    geom, binning, img = _Growable(dev), _Growable(dev), _Growable(dev)
+    hint_key = (dev.index, P, W, H)
+    hint = _binning_hint.get(hint_key, 0)
+    geom, binning, img = _Growable(dev), _Growable(dev, hint + hint // 16), _Growable(dev)
     rendered = ctypes.c_int(0)
     if P != 0:
         out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
@@ -116,6 +130,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy), int(bool(prefiltered)), _ptr(out_color),
                 _ptr(radii), int(bool(debug)), _stream(dev), ctypes.byref(rendered)))
+        _binning_hint[hint_key] = binning.asked
     else:
         out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
         radii = torch.zeros((P,), dtype=torch.int32, device=dev)
