@@ -17,6 +17,8 @@
 //    64-byte-row group of global atomics into the [P][16] accumulator.
 #include "render_common.h"
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // pairs of channels go through the packed-FP32 instructions
+
 // [a summed over lane pairs (l, l+32) in lanes 0-31 | b likewise in lanes 32-63]
 __device__ __forceinline__ float fold32(float a, float b)
 {
@@ -97,7 +99,9 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     bgdot += bg[0] * dpr;
     bgdot += bg[1] * dpg;
     bgdot += bg[2] * dpb;
-    float rec_r = 0.0f, rec_g = 0.0f, rec_b = 0.0f, last_r = 0.0f, last_g = 0.0f, last_b = 0.0f, last_alpha = 0.0f;
+    v2f rec_rg = {0.0f, 0.0f};
+    float rec_b = 0.0f;
+    const v2f dp_rg = {dpr, dpg};
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
     // accumulator slots this lane's 16-lane row ends up holding after the reduce-scatter below
     const int lrow = lane >> 4;
@@ -148,17 +152,21 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
                 const bool live = pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__ballot(live) == 0ull) continue;  // wave-uniform
 
-                // Every lane evaluates the body; dead lanes keep their state and contribute exact zeros
-                // (their G and dL/dalpha are forced to 0, which zeroes every product below).
-                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32, 1 ulp
+                // Every lane evaluates the body.  A dead lane (pixel that does not blend this splat) runs it with
+                // alpha = 0, which leaves its state untouched without a single select: T / (1 - 0) = T, the
+                // colour behind it becomes 0 * colour + 1 * rec = rec, and every partial below is an exact zero
+                // (G and dL/dalpha are forced to 0 as well).
+                const float alpha_l = live ? alpha : 0.0f;
+                const float om = 1.f - alpha_l;
+                const float inv = __builtin_amdgcn_rcpf(om);  // v_rcp_f32, 1 ulp; exactly 1 for a dead lane
                 const float Tn = T * inv;
-                const float w = live ? alpha * Tn : 0.0f;
-                const float nrec_r = last_alpha * last_r + (1.f - last_alpha) * rec_r;
-                const float nrec_g = last_alpha * last_g + (1.f - last_alpha) * rec_g;
-                const float nrec_b = last_alpha * last_b + (1.f - last_alpha) * rec_b;
-                float dL_dalpha = (col.x - nrec_r) * dpr;
-                dL_dalpha += (col.y - nrec_g) * dpg;
-                dL_dalpha += (col.z - nrec_b) * dpb;
+                const float w = alpha_l * Tn;
+                const v2f col_rg = {col.x, col.y};
+                // `rec` is the colour accumulated behind this splat (the reference's accum_rec after its update,
+                // backward.cu:503-513)
+                const v2f d_rg = (col_rg - rec_rg) * dp_rg;
+                float dL_dalpha = d_rg.x + d_rg.y;
+                dL_dalpha += (col.z - rec_b) * dpb;
                 dL_dalpha *= Tn;
                 dL_dalpha += (-T_final * inv) * bgdot;
                 dL_dalpha = live ? dL_dalpha : 0.0f;
@@ -173,17 +181,15 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
                 const float v3 = -0.5f * gdx * dy * dL_dG;      // ACC_CON_B
                 const float v4 = -0.5f * gdy * dy * dL_dG;      // ACC_CON_C
                 const float v5 = Gl * dL_dalpha;                // ACC_OPAC
-                const float v6 = w * dpr;                       // ACC_R
-                const float v7 = w * dpg;                       // ACC_G
+                const v2f v67 = w * dp_rg;                      // ACC_R, ACC_G
+                const float v6 = v67.x, v7 = v67.y;
                 const float v8 = w * dpb;                       // ACC_B
-                T = live ? Tn : T;
-                rec_r = live ? nrec_r : rec_r;
-                rec_g = live ? nrec_g : rec_g;
-                rec_b = live ? nrec_b : rec_b;
-                last_r = live ? col.x : last_r;
-                last_g = live ? col.y : last_g;
-                last_b = live ? col.z : last_b;
-                last_alpha = live ? alpha : last_alpha;
+                // state for the next (nearer) splat: transmittance in front of this one, and the colour behind
+                // the next one = this splat blended over what was behind it (same expression the reference
+                // evaluates one step later from its last_alpha / last_color)
+                T = Tn;
+                rec_rg = alpha_l * col_rg + om * rec_rg;
+                rec_b = alpha_l * col.z + om * rec_b;
 
                 // Wave reduction of the nine partials as a reduce-scatter: two half/row swaps fold the 64 lanes
                 // into 16 columns while spreading the nine values over the four 16-lane rows of three registers,
