@@ -102,7 +102,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     v2f rec_rg = {0.0f, 0.0f};
     float rec_b = 0.0f;
     const v2f dp_rg = {dpr, dpg};
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    const v2f ddel = {(float)(0.5 * W), (float)(0.5 * H)};  // d(pixel offset)/d(ndc)
+    const v2f pix = {pxf, pyf};
     // accumulator slots this lane's 16-lane row ends up holding after the reduce-scatter below
     const int lrow = lane >> 4;
     const int slot0 = lrow == 0 ? ACC_DX : lrow == 1 ? ACC_CON_B : lrow == 2 ? ACC_OPAC : ACC_B;
@@ -145,7 +146,9 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
                 const float4 p = s_rec[j][0];
                 const float4 q = s_rec[j][1];
                 const float4 col = s_rec[j][2];
-                const float dx = p.x - pxf, dy = p.y - pyf;
+                const v2f d = (v2f){p.x, p.y} - pix;  // {dx, dy}
+                const float dx = d.x, dy = d.y;
+                // same evaluation order as the forward pass (and the reference): alpha must come out bit-identical
                 const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
                 const float G = exp_nonpos(power);
                 const float alpha = fminf(0.99f, q.w * G);
@@ -172,14 +175,16 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
                 dL_dalpha = live ? dL_dalpha : 0.0f;
                 const float Gl = live ? G : 0.0f;
                 const float dL_dG = q.w * dL_dalpha;
-                const float gdx = Gl * dx, gdy = Gl * dy;
-                const float dG_ddelx = -gdx * q.x - gdy * q.y;
-                const float dG_ddely = -gdy * q.z - gdx * q.y;
-                const float v0 = dL_dG * dG_ddelx * ddelx_dx;   // ACC_DX
-                const float v1 = dL_dG * dG_ddely * ddely_dy;   // ACC_DY
-                const float v2 = -0.5f * gdx * dx * dL_dG;      // ACC_CON_A
-                const float v3 = -0.5f * gdx * dy * dL_dG;      // ACC_CON_B
-                const float v4 = -0.5f * gdy * dy * dL_dG;      // ACC_CON_C
+                const v2f gd = Gl * d;  // {G dx, G dy}
+                const v2f gx = {gd.x, gd.x}, gy = {gd.y, gd.y};
+                // {dG/ddelx, dG/ddely} = -gdx * {a, b} - gdy * {b, c}
+                const v2f dG = -gx * (v2f){q.x, q.y} - gy * (v2f){q.y, q.z};
+                const v2f v01 = (dL_dG * dG) * ddel;            // ACC_DX, ACC_DY
+                const float v0 = v01.x, v1 = v01.y;
+                const v2f h = -0.5f * gd;
+                const v2f v23 = ((v2f){h.x, h.x} * d) * dL_dG;  // ACC_CON_A, ACC_CON_B
+                const float v2 = v23.x, v3 = v23.y;
+                const float v4 = h.y * dy * dL_dG;              // ACC_CON_C
                 const float v5 = Gl * dL_dalpha;                // ACC_OPAC
                 const v2f v67 = w * dp_rg;                      // ACC_R, ACC_G
                 const float v6 = v67.x, v7 = v67.y;
