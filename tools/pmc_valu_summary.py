@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Vector-ALU load of each kernel from one rocprofv3 --pmc pass over
+SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE.
+
+    python tools/pmc_valu_summary.py gpurun_out/f_pmc_valu > profiles/r01_c4_valu.md
+
+Units on gfx950: SQ_INSTS_* count wave-instructions; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles
+summed over waves; GRBM_GUI_ACTIVE is the sum of the 8 XCDs' busy cycles.  A SIMD issues at most one wave64 FP32
+instruction every 2 cycles with several waves resident, so
+    valu_issue_fraction = SQ_INSTS_VALU * 2 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+is the fraction of the plain-FMA issue peak; transcendental, DPP, lane-swap and packed instructions cost more than
+one slot (tools/probes/valu_rate_probe.hip), so a kernel built from them saturates the vector ALU below 1.0.
+"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+SIMDS = 1024
+
+
+def main():
+    d = sys.argv[1]
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(set)
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path, newline="")):
+            k = r["Kernel_Name"].replace("void ", "")
+            k = k[:k.index("(")] if "(" in k else k
+            tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[k].add(r["Dispatch_Id"])
+    print("| kernel | launches | VALU wave-instr / launch | SALU | LDS | cycles (per XCD) | VALU issue fraction | "
+          "waves resident per SIMD | wave time waiting on memory/LDS counters | wave time stalled at issue |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for k in sorted(tot, key=lambda k: -tot[k].get("GRBM_GUI_ACTIVE", 0)):
+        c, n = tot[k], len(launches[k])
+        cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8 / n
+        if cyc <= 0 or c.get("SQ_INSTS_VALU", 0) <= 0 or k.startswith("__amd") or k.startswith("at::"):
+            continue
+        valu = c["SQ_INSTS_VALU"] / n
+        wave_q = c.get("SQ_WAVE_CYCLES", 0) / n
+        print("| `%s` | %d | %.3g | %.3g | %.3g | %.3g | %.2f | %.1f | %.0f %% | %.0f %% |" % (
+            k, n, valu, c.get("SQ_INSTS_SALU", 0) / n, c.get("SQ_INSTS_LDS", 0) / n, cyc,
+            valu * 2 / (SIMDS * cyc), wave_q * 4 / (SIMDS * cyc),
+            100 * c.get("SQ_WAIT_ANY", 0) / n / wave_q if wave_q else 0,
+            100 * c.get("SQ_WAIT_INST_ANY", 0) / n / wave_q if wave_q else 0))
+
+
+if __name__ == "__main__":
+    main()
