@@ -41,6 +41,11 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, const float* __restrict__ s
     return make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
 }
 
+// EAGER: the common training shape (scales + rotations, full SH rows of 16 coefficients at degree 3).  All of a
+// Gaussian's inputs are requested before any arithmetic: the culling tests that decide whether they are needed
+// depend on one another (position -> covariance -> footprint -> colour), and waiting for each answer before asking
+// for the next operand costs a memory round trip per stage.  A culled Gaussian's few extra bytes are cheaper.
+template <bool EAGER>
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float mod,
     const float* __restrict__ rots, const float* __restrict__ opac, const float* __restrict__ shs,
@@ -55,6 +60,17 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     int my_radius = 0;
     if (idx < P) {
         const float px = means[3 * idx], py = means[3 * idx + 1], pz = means[3 * idx + 2];
+        float4 e_sh[EAGER ? 12 : 1];
+        float4 e_q = make_float4(0, 0, 0, 0);
+        float e_s0 = 0, e_s1 = 0, e_s2 = 0, e_op = 0;
+        if (EAGER) {
+            e_q = ((const float4*)rots)[idx];
+            e_s0 = scales[3 * idx]; e_s1 = scales[3 * idx + 1]; e_s2 = scales[3 * idx + 2];
+            e_op = opac[idx];
+            const float4* row = (const float4*)(shs + (size_t)48 * idx);
+#pragma unroll
+            for (int k = 0; k < 12; k++) e_sh[k] = row[k];
+        }
         const float3 pv = xform43(px, py, pz, view);
         if (pv.z <= 0.2f) {
             // The reference aborts the kernel here when `prefiltered` is set
@@ -66,7 +82,9 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
             const float pw = 1.0f / (ph.w + 0.0000001f);
             const float projx = ph.x * pw, projy = ph.y * pw;
             float c6[6];
-            if (cov_pre) {
+            if (EAGER) {
+                cov3d_from_scale_rot(e_s0, e_s1, e_s2, mod, e_q.x, e_q.y, e_q.z, e_q.w, c6);
+            } else if (cov_pre) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) c6[k] = cov_pre[6 * (size_t)idx + k];
             } else {
@@ -93,7 +111,12 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
                 if (area != 0) {
                     float3 col;
                     uint32_t cb = 0;
-                    if (col_pre) {
+                    if (EAGER) {
+                        float3 d = make_float3(px - campos[0], py - campos[1], pz - campos[2]);
+                        const float len = sqrtf(f3_dot(d, d));
+                        d = make_float3(d.x / len, d.y / len, d.z / len);
+                        col = sh_to_rgb(3, (const float*)e_sh, d, cb);
+                    } else if (col_pre) {
                         col = make_float3(col_pre[3 * (size_t)idx], col_pre[3 * (size_t)idx + 1],
                                           col_pre[3 * (size_t)idx + 2]);
                     } else {
@@ -104,7 +127,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
                     }
                     float4* r = rec + 4 * (size_t)idx;
                     r[0] = make_float4(ix, iy, k.c * dinv, -k.b * dinv);
-                    r[1] = make_float4(k.a * dinv, opac[idx], col.x, col.y);
+                    r[1] = make_float4(k.a * dinv, EAGER ? e_op : opac[idx], col.x, col.y);
                     r[2] = make_float4(col.z, 0.0f, 0.0f, 0.0f);
                     depth[idx] = pv.z;
                     rect[idx] = make_uint2(x0 | (x1 << 16), y0 | (y1 << 16));
@@ -142,9 +165,16 @@ void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* 
                                uint32_t* block_sums, uint32_t* misc)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales, mod, rots,
+    const bool eager = !cov_pre && !col_pre && shs && scales && rots && D == 3 && M == 16 && (uintptr_t)shs % 16 == 0 &&
+                       (uintptr_t)rots % 16 == 0;
+    if (eager)
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales, mod, rots,
                        opac, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered, radii, rec, depth, rect, tiles, clamped,
                        block_sums, misc);
+    else
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales,
+                           mod, rots, opac, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered,
+                           radii, rec, depth, rect, tiles, clamped, block_sums, misc);
 }
 
 void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const float* view, uint8_t* present)
