@@ -291,6 +291,19 @@ __device__ __forceinline__ Cov2D cov2d_eval(float mx, float my, float mz, const 
     return k;
 }
 
+// 16-byte streaming accesses for data touched once per pass (SH rows, gradient tensors, optimiser state): the
+// non-temporal hint keeps such streams from evicting each other and the reused state from the caches.
+typedef float ngs_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load4(const float* p)
+{
+    const ngs_v4f v = __builtin_nontemporal_load((const ngs_v4f*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stream_store4(float* p, float4 v)
+{
+    __builtin_nontemporal_store((ngs_v4f){v.x, v.y, v.z, v.w}, (ngs_v4f*)p);
+}
+
 // Spherical-harmonics constants (cuda_rasterizer/auxiliary.h:22-39).
 #define NGS_SH_C0 0.28209479177387814f
 #define NGS_SH_C1 0.4886025119029199f

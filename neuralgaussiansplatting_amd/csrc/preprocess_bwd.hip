@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
                 const int f = t * 64 + lane, g = f / (SH_ROW / 4), c = f - g * (SH_ROW / 4);
                 if (wave_first + g < P && ((vis_mask >> g) & 1ull))
                     *(float4*)(wrows + g * SH_ROW_LDS + c * 4) =
-                        ((const float4*)(shs + (size_t)(wave_first + g) * SH_ROW))[c];
+                        stream_load4(shs + (size_t)(wave_first + g) * SH_ROW + 4 * c);
             }
         }
         __syncthreads();
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
             if (wave_first + g < P) {
                 float4 v = make_float4(0, 0, 0, 0);
                 if ((vis_mask >> g) & 1ull) v = *(const float4*)(wrows + g * SH_ROW_LDS + c * 4);
-                ((float4*)(dL_dsh + (size_t)(wave_first + g) * SH_ROW))[c] = v;
+                stream_store4(dL_dsh + (size_t)(wave_first + g) * SH_ROW + 4 * c, v);
             }
         }
     }

@@ -67,6 +67,8 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
             e_q = ((const float4*)rots)[idx];
             e_s0 = scales[3 * idx]; e_s1 = scales[3 * idx + 1]; e_s2 = scales[3 * idx + 2];
             e_op = opac[idx];
+            // plain (cached) loads: a lane reads its 192-byte row 16 bytes at a time and relies on the cache for
+            // the rest of each line
             const float4* row = (const float4*)(shs + (size_t)48 * idx);
 #pragma unroll
             for (int k = 0; k < 12; k++) e_sh[k] = row[k];

@@ -72,8 +72,8 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void sh_from_views_kernel(
         for (int t = 0; t < SH_ROW * 64 / 4 / 64; t++) {
             const int f = t * 64 + lane, g = f / (SH_ROW / 4), c = f - g * (SH_ROW / 4);
             if (wave_first + g < P)
-                ((float4*)(dL_dsh + (size_t)(wave_first + g) * SH_ROW))[c] =
-                    *(const float4*)(wrows + g * SH_ROW_LDS + c * 4);
+                stream_store4(dL_dsh + (size_t)(wave_first + g) * SH_ROW + 4 * c,
+                              *(const float4*)(wrows + g * SH_ROW_LDS + c * 4));
         }
     } else if (idx < P) {
         float3* out = (float3*)(dL_dsh + (size_t)3 * M * i);

@@ -198,6 +198,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void ssim_l1_backward_kernel(
 // The scalars are formed on the host in double and rounded to float once, as torch does with its Python floats:
 // one_minus_beta1 = float(1 - beta1), one_minus_beta2 = float(1 - beta2), bc2_sqrt = float(sqrt(1 - beta2^t)), and a
 // group's `step` below is float(lr / (1 - beta1^t)).
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 struct AdamConst {
     float one_minus_beta1, beta2, one_minus_beta2, eps, bc2_sqrt, grad_scale;
 };
@@ -228,17 +230,21 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(long long n, float* __re
         // position inside the period: 32-bit arithmetic whenever the index fits (a 64-bit modulo is ~100 instructions)
         unsigned r = i4 < 0x7fffffffLL ? (unsigned)i4 % (unsigned)period : (unsigned)(i4 % period);
         if (i4 + 4 <= n) {
-            float4 p = *(const float4*)(param + i4), g = *(const float4*)(grad + i4);
-            float4 m = *(const float4*)(exp_avg + i4), v = *(const float4*)(exp_avg_sq + i4);
-            float* pe = &p.x; float* ge = &g.x; float* me = &m.x; float* ve = &v.x;
+            // every byte is touched once per step: non-temporal accesses keep the streams from evicting each other
+            v4f p = __builtin_nontemporal_load((const v4f*)(param + i4));
+            v4f g = __builtin_nontemporal_load((const v4f*)(grad + i4));
+            v4f m = __builtin_nontemporal_load((const v4f*)(exp_avg + i4));
+            v4f v = __builtin_nontemporal_load((const v4f*)(exp_avg_sq + i4));
+            float pe[4] = {p.x, p.y, p.z, p.w}, ge[4] = {g.x, g.y, g.z, g.w}, me[4] = {m.x, m.y, m.z, m.w},
+                  ve[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 pe[e] = adam_update(pe[e], ge[e] * k.grad_scale, me[e], ve[e], (int)r < head ? step_head : step_tail, k);
                 r = r + 1 == (unsigned)period ? 0u : r + 1;
             }
-            *(float4*)(param + i4) = p;
-            *(float4*)(exp_avg + i4) = m;
-            *(float4*)(exp_avg_sq + i4) = v;
+            __builtin_nontemporal_store((v4f){pe[0], pe[1], pe[2], pe[3]}, (v4f*)(param + i4));
+            __builtin_nontemporal_store((v4f){me[0], me[1], me[2], me[3]}, (v4f*)(exp_avg + i4));
+            __builtin_nontemporal_store((v4f){ve[0], ve[1], ve[2], ve[3]}, (v4f*)(exp_avg_sq + i4));
         } else {
             for (long long i = i4; i < n; i++) {
                 float m = exp_avg[i], v = exp_avg_sq[i];
