@@ -130,6 +130,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy), int(bool(prefiltered)), _ptr(out_color),
                 _ptr(radii), int(bool(debug)), _stream(dev), ctypes.byref(rendered)))
+        if len(_binning_hint) > 256:  # shapes keep changing (densification): forget the old ones
+            _binning_hint.clear()
         _binning_hint[hint_key] = binning.asked
     else:
         out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
