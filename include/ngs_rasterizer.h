@@ -144,6 +144,37 @@ int ngs_adam_step_activated(int P, float* const raw[3], const float* const grad[
                             void* stream);
 
 /*
+ * Index-map path of the reference's second rasterizer (r2 = submodules/rasterizer2), the operator behind
+ * rasterizer2._GetIdxMap2 (r2/rasterizer2/__init__.py:31-138; binding r2/rasterize_points.cu:183-295).
+ *
+ * ngs_idxmap_forward takes the pointer list of CudaRasterizer::Rasterizer::getidxmap
+ * (r2/cuda_rasterizer/rasterizer.h:61-85, rasterizer_impl.cu:851-984) with the three buffer callbacks replaced by
+ * one caller-owned workspace of ngs_idxmap_workspace_bytes(width, height) bytes (the reference's three buffers
+ * never leave its binding either), plus a stream.  Every Gaussian centre in front of the near plane and inside the
+ * image is splatted as a square of half-width 3/depth pixels; each pixel shows the nearest centre:
+ *   out_idx [H][W]: its index or -1;  out_color [H][W][3]: its unit view direction;  out_depth [H][W];
+ *   out_feature [H][W][64]: {depth, 24-value positional encoding of the direction, features 25..63 of the
+ *   Gaussian's feature_vector [P][64]}.
+ * Every output element is written (zeros where no centre landed), so the caller need not zero-fill.  normal,
+ * scales, rotations, sh, M and the tan_fov values are accepted and ignored, as in the reference; radii ([P], 1 for
+ * a Gaussian that was splatted) and num_rendered (the number of (Gaussian, pixel) entries the reference would have
+ * sorted, its return value) may be NULL -- asking for num_rendered costs a host synchronisation.
+ *
+ * ngs_idxmap_backward = getidxmap_backward (rasterizer.h:87-96, rasterizer_impl.cu:986-1007):
+ * dL_dfeature_vector[g][25..63] = sum over the pixels showing g of dL_dout_feature[pixel][25..63]; the whole
+ * [P][64] output is written.  The reference adds without atomics from concurrent threads; here the sum is exact up
+ * to float addition order.
+ */
+size_t ngs_idxmap_workspace_bytes(int width, int height);
+int ngs_idxmap_forward(int P, int M, int width, int height, const float* means3D, const float* normal,
+                       const float* scales, const float* rotations, const float* viewmatrix, const float* projmatrix,
+                       float tan_fovx, float tan_fovy, const float* feature_vector, const float* sh,
+                       const float* campos, int* out_idx, float* out_color, float* out_depth, float* out_feature,
+                       int* radii, char* workspace, int debug, void* stream, int* num_rendered);
+int ngs_idxmap_backward(int P, int width, int height, const float* means3D, const float* campos, const int* out_idx,
+                        const float* dL_dout_feature, float* dL_dfeature_vector, int debug, void* stream);
+
+/*
  * Introspection for parity tests: byte offsets (relative to the 256-byte
  * aligned base of each buffer) of the intermediate arrays, in this order:
  *  geometry[10]: splat_record(16 floats per Gaussian: x, y, conic a, b, c, opacity, r, g, b, 7 unused),

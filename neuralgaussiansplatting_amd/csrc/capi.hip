@@ -40,13 +40,14 @@ static int fail(const char* what, const char* detail)
 // ---------------------------------------------------------------------------
 enum {
     ST_PREPROCESS, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SEGSORT, ST_RENDER_FWD,
-    ST_BWD_ZERO, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_SH_VIEWS, ST_LOSS, ST_ADAM_FLAT, ST_ADAM_ACTIVATED, ST_COUNT
+    ST_BWD_ZERO, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_SH_VIEWS, ST_LOSS, ST_ADAM_FLAT, ST_ADAM_ACTIVATED,
+    ST_IDXMAP_FWD, ST_IDXMAP_BWD, ST_COUNT
 };
 static const char* const g_stage_names[ST_COUNT] = {
     "preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort_tile_bits", "tile_ranges", "segment_sort_depth",
     "render_fwd",
     "zero_accumulator", "render_bwd", "preprocess_bwd", "sh_gradient_from_views", "l1_ssim_loss", "adam_identity_groups",
-    "adam_activated_groups"};
+    "adam_activated_groups", "idxmap_forward", "idxmap_backward"};
 #define PROF_RING 32
 struct ProfSlot {
     hipEvent_t ev[ST_COUNT][2];
@@ -515,6 +516,68 @@ extern "C" int ngs_adam_step_activated(int P, float* const raw[3], const float* 
     prof_end(ps, ST_ADAM_ACTIVATED, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("stage Adam (activated groups)", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" size_t ngs_idxmap_workspace_bytes(int width, int height)
+{
+    return width > 0 && height > 0 ? ngs_idxmap_workspace_size(width, height) : 0;
+}
+
+extern "C" int ngs_idxmap_forward(int P, int M, int width, int height, const float* means3D, const float* normal,
+                                  const float* scales, const float* rotations, const float* viewmatrix,
+                                  const float* projmatrix, float tan_fovx, float tan_fovy,
+                                  const float* feature_vector, const float* sh, const float* campos, int* out_idx,
+                                  float* out_color, float* out_depth, float* out_feature, int* radii, char* workspace,
+                                  int debug, void* stream, int* num_rendered)
+{
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    // accepted for signature parity with the reference, which does not read them either (rasterizer_impl.cu:851-984)
+    (void)M; (void)normal; (void)scales; (void)rotations; (void)tan_fovx; (void)tan_fovy; (void)sh;
+    if (num_rendered) *num_rendered = 0;
+    if (P < 0 || width <= 0 || height <= 0) return fail("ngs_idxmap_forward", "bad sizes");
+    if (width > 32767 || height > 32767)
+        return fail("ngs_idxmap_forward", "image too large (the reference walks pixels with 16-bit signed counters)");
+    if (!out_idx || !out_color || !out_depth || !out_feature || !workspace)
+        return fail("ngs_idxmap_forward", "missing required pointer");
+    if (P > 0 && (!means3D || !viewmatrix || !projmatrix || !feature_vector || !campos))
+        return fail("ngs_idxmap_forward", "missing required pointer");
+    if (((uintptr_t)out_feature | (uintptr_t)feature_vector) % 16 != 0 || (uintptr_t)workspace % 8 != 0)
+        return fail("ngs_idxmap_forward", "feature arrays must be 16-byte aligned, the workspace 8-byte aligned");
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_IDXMAP_FWD, st);
+    ngs_launch_idxmap_forward(st, P, width, height, means3D, viewmatrix, projmatrix, campos, feature_vector, workspace,
+                              out_idx, out_color, out_depth, out_feature, radii);
+    prof_end(ps, ST_IDXMAP_FWD, st);
+    NGS_STAGE("index map");
+    if (num_rendered) {  // only a caller that wants the entry count pays for the synchronisation
+        uint32_t n = 0;
+        NGS_HIP(hipMemcpyAsync(&n, workspace + (size_t)width * height * 8, sizeof n, hipMemcpyDeviceToHost, st));
+        NGS_HIP(hipStreamSynchronize(st));
+        *num_rendered = (int)n;
+    }
+    return 0;
+}
+
+extern "C" int ngs_idxmap_backward(int P, int width, int height, const float* means3D, const float* campos,
+                                   const int* out_idx, const float* dL_dout_feature, float* dL_dfeature_vector,
+                                   int debug, void* stream)
+{
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    (void)means3D; (void)campos;  // unused by the reference as well (rasterizer_impl.cu:820-847)
+    if (P < 0 || width <= 0 || height <= 0) return fail("ngs_idxmap_backward", "bad sizes");
+    if (P == 0) return 0;
+    if (!out_idx || !dL_dout_feature || !dL_dfeature_vector) return fail("ngs_idxmap_backward", "missing required pointer");
+    if (((uintptr_t)dL_dout_feature | (uintptr_t)dL_dfeature_vector) % 16 != 0)
+        return fail("ngs_idxmap_backward", "feature arrays must be 16-byte aligned");
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_IDXMAP_BWD, st);
+    NGS_HIP(hipMemsetAsync(dL_dfeature_vector, 0, (size_t)P * 64 * sizeof(float), st));
+    ngs_launch_idxmap_backward(st, P, width, height, out_idx, dL_dout_feature, dL_dfeature_vector);
+    prof_end(ps, ST_IDXMAP_BWD, st);
+    NGS_STAGE("index map backward");
     return 0;
 }
 

@@ -1,0 +1,170 @@
+// Index-map path of the reference's second rasterizer (r2 = submodules/rasterizer2): every Gaussian centre is
+// splatted as a screen-space square of half-width 3/depth pixels and each pixel keeps the NEAREST centre; the
+// outputs are the winner's index, its view direction (raw and as a 24-value positional encoding), its depth and
+// features 25..63 of its 64-value feature vector (r2/cuda_rasterizer/rasterizer_impl.cu:851-984).
+//
+// The reference gets there with a prefix scan, one (pixel | depth) key per covered pixel, a 63-bit radix sort of
+// all of them, a range search and a gather (rasterizer_impl.cu:914-981).  The first entry of a pixel's sorted range
+// is the entry with the smallest depth bits, ties going to the lower Gaussian index (stable sort, entries emitted
+// in index order) -- which is the minimum of the 64-bit word (depth bits << 32 | index).  So here each covered
+// pixel takes one 64-bit atomic minimum into a W x H buffer and a second kernel resolves the winners: no scan,
+// no keys, no sort, no ranges, and the only scratch is 8 bytes per pixel.
+#include "ngs_common.h"
+
+#define IDX_FEATURES 64      // r2/cuda_rasterizer/config.h:3
+#define IDX_FREQS 4          // r2/cuda_rasterizer/auxiliary.h:33
+#define IDX_FIRST_COPIED 25  // features 25..63 come from the Gaussian (rasterizer_impl.cu:797-799)
+#define IDX_PI 3.14159265358979323846f
+
+// r2/cuda_rasterizer/auxiliary.h:38-41 (double arithmetic, rounded once to float)
+__device__ __forceinline__ float idx_ndc_to_pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// Per-Gaussian stage (r2/cuda_rasterizer/raster.cu:10-66) fused with the "key emission": one lane per Gaussian.
+__global__ __launch_bounds__(NGS_GAUSS_BLOCK) void idxmap_splat_kernel(int P, int W, int H,
+                                                                      const float* __restrict__ means,
+                                                                      const float* __restrict__ view,
+                                                                      const float* __restrict__ proj,
+                                                                      unsigned long long* __restrict__ zbuf,
+                                                                      int* __restrict__ radii,
+                                                                      uint32_t* __restrict__ counter)
+{
+    const int idx = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
+    uint32_t touched = 0;
+    if (idx < P) {
+        int visible = 0;
+        const float px = means[3 * idx], py = means[3 * idx + 1], pz = means[3 * idx + 2];
+        const float4 ph = xform44(px, py, pz, proj);
+        const float pw = 1.0f / (ph.w + 0.0000001f);
+        const float projx = ph.x * pw, projy = ph.y * pw;
+        const float3 pv = xform43(px, py, pz, view);
+        if (pv.z > 0.2f) {
+            const float fx = idx_ndc_to_pix(projx, W), fy = idx_ndc_to_pix(projy, H);
+            const int cx = (int)fx, cy = (int)fy;  // v_cvt_i32_f32: truncates like the reference's conversion
+            const float rad = 3.0f / pv.z;         // raster.cu:46,85
+            const int x0 = (int)fmaxf(0.0f, fx - rad), y0 = (int)fmaxf(0.0f, fy - rad);
+            const int x1 = (int)fminf((float)W, fx + rad + 1.0f), y1 = (int)fminf((float)H, fy + rad + 1.0f);
+            if (!(cx < 0 || cx >= W || cy < 0 || cy >= H)) {
+                visible = 1;
+                touched = (uint32_t)((x1 - x0) * (y1 - y0));
+                const unsigned long long key = ((unsigned long long)__float_as_uint(pv.z) << 32) | (uint32_t)idx;
+                for (int y = y0; y < y1; y++)
+                    for (int x = x0; x < x1; x++) {
+                        unsigned long long* cell = zbuf + (size_t)y * W + x;
+                        // values only ever decrease, so a cell already below the key can be skipped unlocked
+                        if (key < *(volatile unsigned long long*)cell) atomicMin(cell, key);
+                    }
+            }
+        }
+        if (radii) radii[idx] = visible;
+    }
+    const uint32_t ws = wave_sum_u32(touched);
+    if ((threadIdx.x & 63) == 0 && ws) atomicAdd(counter, ws);
+}
+
+// 16 lanes per pixel, lane c owning floats 4c..4c+3 of the pixel's 64-float feature row: every output row leaves
+// as one coalesced 256-byte run.  Writes every element of every output (zeros where no centre landed).
+__global__ __launch_bounds__(256) void idxmap_resolve_kernel(int W, int H, const unsigned long long* __restrict__ zbuf,
+                                                             const float* __restrict__ means,
+                                                             const float* __restrict__ campos,
+                                                             const float* __restrict__ feature_vector,
+                                                             int* __restrict__ out_idx, float* __restrict__ out_color,
+                                                             float* __restrict__ out_depth,
+                                                             float* __restrict__ out_feature)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t pix = t >> 4;
+    const int c = (int)(t & 15);
+    if (pix >= (size_t)W * H) return;
+    const unsigned long long cell = zbuf[pix];
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (cell == ~0ull) {
+        if (c == 0) {
+            out_idx[pix] = -1;
+            out_color[3 * pix] = 0.0f; out_color[3 * pix + 1] = 0.0f; out_color[3 * pix + 2] = 0.0f;
+            out_depth[pix] = 0.0f;
+        }
+    } else {
+        const uint32_t g = (uint32_t)cell;
+        const float depth = __uint_as_float((uint32_t)(cell >> 32));
+        // view direction of the winner (rasterizer_impl.cu:768-771)
+        float3 d = make_float3(means[3 * (size_t)g] - campos[0], means[3 * (size_t)g + 1] - campos[1],
+                               means[3 * (size_t)g + 2] - campos[2]);
+        const float len = sqrtf(f3_dot(d, d));
+        d = make_float3(d.x / len, d.y / len, d.z / len);
+        if (c == 0) {
+            out_idx[pix] = (int)g;
+            out_color[3 * pix] = d.x; out_color[3 * pix + 1] = d.y; out_color[3 * pix + 2] = d.z;
+            out_depth[pix] = depth;
+        }
+        const float* fv = feature_vector + (size_t)g * IDX_FEATURES;
+        if (c >= 7) {
+            out = *(const float4*)(fv + 4 * c);
+        } else {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = 4 * c + k;
+                if (e == 0) {
+                    v[k] = depth;
+                } else if (e < IDX_FIRST_COPIED) {
+                    // positional encoding (rasterizer_impl.cu:26-42): element 1 + dim*8 + freq*2 (+1 for the cosine)
+                    const int p = e - 1, dim = p >> 3, fr = (p & 7) >> 1;
+                    const float x = dim == 0 ? d.x : dim == 1 ? d.y : d.z;
+                    const float arg = (float)(1 << fr) * IDX_PI * x;
+                    v[k] = (p & 1) ? cosf(arg) : sinf(arg);
+                } else {
+                    v[k] = fv[e];
+                }
+            }
+            out = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    *(float4*)(out_feature + pix * IDX_FEATURES + 4 * c) = out;
+}
+
+// Backward (rasterizer_impl.cu:820-847): the gradient of feature-map elements 25..63 of every pixel flows to the
+// Gaussian the pixel shows.  Same 16-lanes-per-pixel mapping; float atomics make the sum well defined (the
+// reference adds from concurrent threads without them).  dL_dfeature_vector is zeroed by the entry point first.
+__global__ __launch_bounds__(256) void idxmap_backward_kernel(int P, int W, int H, const int* __restrict__ out_idx,
+                                                              const float* __restrict__ dL_dfeature,
+                                                              float* __restrict__ dL_dfeature_vector)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t pix = t >> 4;
+    const int c = (int)(t & 15);
+    if (pix >= (size_t)W * H || c < IDX_FIRST_COPIED / 4) return;
+    const int g = out_idx[pix];
+    if (g < 0 || g >= P) return;
+    const float4 v = *(const float4*)(dL_dfeature + pix * IDX_FEATURES + 4 * c);
+    float* dst = dL_dfeature_vector + (size_t)g * IDX_FEATURES + 4 * c;
+    if (4 * c >= IDX_FIRST_COPIED) atomicAdd(dst, v.x);
+    atomicAdd(dst + 1, v.y);
+    atomicAdd(dst + 2, v.z);
+    atomicAdd(dst + 3, v.w);
+}
+
+size_t ngs_idxmap_workspace_size(int W, int H) { return (size_t)W * H * 8 + 256; }
+
+void ngs_launch_idxmap_forward(hipStream_t s, int P, int W, int H, const float* means, const float* view,
+                               const float* proj, const float* campos, const float* feature_vector, char* workspace,
+                               int* out_idx, float* out_color, float* out_depth, float* out_feature, int* radii)
+{
+    unsigned long long* zbuf = (unsigned long long*)workspace;
+    uint32_t* counter = (uint32_t*)(workspace + (size_t)W * H * 8);
+    (void)hipMemsetAsync(zbuf, 0xFF, (size_t)W * H * 8, s);
+    (void)hipMemsetAsync(counter, 0, 256, s);
+    if (P > 0)
+        hipLaunchKernelGGL(idxmap_splat_kernel, dim3((P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK),
+                           dim3(NGS_GAUSS_BLOCK), 0, s, P, W, H, means, view, proj, zbuf, radii, counter);
+    const size_t threads = (size_t)W * H * 16;
+    hipLaunchKernelGGL(idxmap_resolve_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, W, H, zbuf,
+                       means, campos, feature_vector, out_idx, out_color, out_depth, out_feature);
+}
+
+void ngs_launch_idxmap_backward(hipStream_t s, int P, int W, int H, const int* out_idx, const float* dL_dfeature,
+                                float* dL_dfeature_vector)
+{
+    const size_t threads = (size_t)W * H * 16;
+    hipLaunchKernelGGL(idxmap_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P, W, H,
+                       out_idx, dL_dfeature, dL_dfeature_vector);
+}

@@ -180,6 +180,14 @@ void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const 
                                float grad_scale, const float* dL_dmean2D, const int* radii, float* grad_accum,
                                float* denom, int* max_radii);
 
+// idxmap.hip: nearest-centre index map of the reference's second rasterizer and its backward.
+size_t ngs_idxmap_workspace_size(int W, int H);
+void ngs_launch_idxmap_forward(hipStream_t s, int P, int W, int H, const float* means, const float* view,
+                               const float* proj, const float* campos, const float* feature_vector, char* workspace,
+                               int* out_idx, float* out_color, float* out_depth, float* out_feature, int* radii);
+void ngs_launch_idxmap_backward(hipStream_t s, int P, int W, int H, const int* out_idx, const float* dL_dfeature,
+                                float* dL_dfeature_vector);
+
 #ifdef __HIPCC__
 // ---------------------------------------------------------------------------
 // Device math shared by preprocess forward and backward.  Matrices are stored

@@ -20,8 +20,8 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "ngs_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ngs_oracle.c", "ngs_oracle_idxmap.c"))
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libngs_oracle.so"])
     return _LIB_PATH
 
@@ -35,6 +35,7 @@ def lib():
         _lib.ngs_oracle_higher_msb.restype = ctypes.c_uint32
         _lib.ngs_oracle_threads.restype = ctypes.c_int
         _lib.ngs_oracle_preprocess.restype = ctypes.c_int
+        _lib.ngs_oracle_idxmap_forward.restype = ctypes.c_longlong
     return _lib
 
 
@@ -173,3 +174,36 @@ def backward(s, dL_dpix, means3D, viewmatrix, projmatrix, campos, bg, tanfovx, t
                                      _p(g["dL_dmeans2D"]), _p(g["dL_dmeans3D"]), _p(g["dL_dcolors"]),
                                      _p(g["dL_dcov3D"]), _p(g["dL_dsh"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
     return g
+
+
+IDXMAP_FEATURES = 64  # submodules/rasterizer2/cuda_rasterizer/config.h:3
+
+
+def idxmap_forward(means3D, viewmatrix, projmatrix, feature_vector, campos, W, H):
+    """The reference's index-map path (ngs_oracle_idxmap.c).  Returns a dict with the four maps, the entry count
+    and the per-Gaussian intermediates."""
+    means3D, viewmatrix, projmatrix, feature_vector, campos = map(_f32, (means3D, viewmatrix, projmatrix,
+                                                                        feature_vector, campos))
+    P = means3D.shape[0]
+    out = dict(idx=np.zeros((H, W), np.int32), color=np.zeros((H, W, 3), np.float32),
+               depth=np.zeros((H, W), np.float32), feature=np.zeros((H, W, IDXMAP_FEATURES), np.float32),
+               radii=np.zeros(P, np.int32), depths=np.zeros(P, np.float32), pixels=np.zeros((P, 2), np.int32),
+               touched=np.zeros(P, np.uint32))
+    R = lib().ngs_oracle_idxmap_forward(P, int(W), int(H), _p(means3D), _p(viewmatrix), _p(projmatrix),
+                                        _p(feature_vector), _p(campos), _p(out["idx"]), _p(out["color"]),
+                                        _p(out["depth"]), _p(out["feature"]), _p(out["radii"]), _p(out["depths"]),
+                                        _p(out["pixels"]), _p(out["touched"]))
+    if R < 0:
+        raise MemoryError("idxmap oracle: allocation failed")
+    out["num_rendered"] = int(R)
+    return out
+
+
+def idxmap_backward(P, idx, dL_dfeature):
+    """-> dL_dfeature_vector [P, 64]"""
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    dL_dfeature = _f32(dL_dfeature)
+    H, W = idx.shape
+    out = np.zeros((P, IDXMAP_FEATURES), np.float32)
+    lib().ngs_oracle_idxmap_backward(int(P), int(W), int(H), _p(idx), _p(dL_dfeature), _p(out))
+    return out

@@ -1,0 +1,123 @@
+"""GPU parity of the index-map operators (through the C ABI) against the checker's restatement of the reference's
+scan / key / sort / range pipeline.  Bar: index map, depth map and the copied features bit-exact; view direction
+and its positional encoding within 2e-6 (device vs host sin/cos/sqrt); the backward sum within float addition order."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from test_idxmap_cpu import idxmap_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def r2():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from neuralgaussiansplatting_amd import rasterizer2
+    rasterizer2._C._lib()
+    return rasterizer2
+
+
+def run_hip(r2, means, vm, pm, fv, campos, W, H, debug=False):
+    t = lambda a: torch.tensor(a, device=DEV)
+    e = torch.empty(0, device=DEV)
+    return r2._C.get_idxmap2(e, t(means), e, e, e, t(vm), t(pm), 0.36, 0.36, H, W, t(fv), e, t(campos), debug)
+
+
+CASES = {
+    "orbit_view": dict(P=3000, W=80, H=56),
+    "camera_close": dict(P=3000, W=80, H=56, eye=(0.3, 0.2, -2.2)),
+    "inside_cloud_big_squares": dict(P=1500, W=64, H=48, eye=(0.1, 0.05, -0.5)),
+    "ragged_size": dict(P=700, W=37, H=23, seed=9),
+    "sparse": dict(P=40, W=64, H=64, seed=2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_idxmap_forward_matches_oracle(name, r2, oracle):
+    c = dict(CASES[name])
+    W, H = c["W"], c["H"]
+    means, vm, pm, fv, campos = idxmap_case(**c)
+    o = oracle.idxmap_forward(means, vm, pm, fv, campos, W, H)
+    n, idx, col, dep, feat = run_hip(r2, means, vm, pm, fv, campos, W, H)
+    assert n == o["num_rendered"]
+    np.testing.assert_array_equal(idx.cpu().numpy(), o["idx"])
+    np.testing.assert_array_equal(dep.cpu().numpy().view(np.uint32), o["depth"].view(np.uint32))
+    f = feat.cpu().numpy()
+    np.testing.assert_array_equal(f[..., 25:], o["feature"][..., 25:])
+    np.testing.assert_array_equal(f[..., 0].view(np.uint32), o["feature"][..., 0].view(np.uint32))
+    np.testing.assert_allclose(f[..., 1:25], o["feature"][..., 1:25], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(col.cpu().numpy(), o["color"], rtol=0, atol=2e-6)
+    hit = o["idx"] >= 0
+    assert hit.any() and (not hit.all() or name == "inside_cloud_big_squares")
+
+
+def test_idxmap_debug_mode_and_no_count(r2, oracle):
+    W, H = 48, 40
+    means, vm, pm, fv, campos = idxmap_case(500, W, H)
+    a = run_hip(r2, means, vm, pm, fv, campos, W, H, debug=True)
+    t = lambda x: torch.tensor(x, device=DEV)
+    e = torch.empty(0, device=DEV)
+    b = r2._C.get_idxmap2(e, t(means), e, e, e, t(vm), t(pm), 0.36, 0.36, H, W, t(fv), e, t(campos), False,
+                          count_entries=False)
+    assert b[0] == -1 and a[0] > 0
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
+
+
+def test_idxmap_backward_matches_oracle(r2, oracle):
+    W, H = 80, 56
+    means, vm, pm, fv, campos = idxmap_case(3000, W, H, eye=(0.3, 0.2, -2.2))
+    o = oracle.idxmap_forward(means, vm, pm, fv, campos, W, H)
+    g = np.random.RandomState(3).randn(H, W, 64).astype(np.float32)
+    want = oracle.idxmap_backward(len(means), o["idx"], g)
+    got = r2._C.get_idxmap_backward2(torch.tensor(means, device=DEV), H, W, torch.tensor(campos, device=DEV),
+                                     torch.tensor(o["idx"], device=DEV), torch.tensor(g, device=DEV), False)[0]
+    got = got.cpu().numpy()
+    assert not got[:, :25].any()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
+    assert np.abs(want).max() > 1.0
+
+
+def test_idxmap_autograd_entry_point(r2, oracle):
+    """GaussianRasterizer2 under autograd: the feature vector's gradient is the scatter-add of the feature map's
+    gradient, every other input gets zeros (rasterizer2/__init__.py:109-137)."""
+    W, H = 64, 48
+    means, vm, pm, fv, campos = idxmap_case(900, W, H)
+    t = lambda a: torch.tensor(a, device=DEV)
+    settings = r2.GaussianRasterizationSettings2(
+        image_height=H, image_width=W, tanfovx=0.36, tanfovy=0.27, bg=torch.zeros(3, device=DEV), scale_modifier=1.0,
+        viewmatrix=t(vm), projmatrix=t(pm), sh_degree=0, campos=t(campos), prefiltered=False, debug=False)
+    m = t(means).requires_grad_(True)
+    f = t(fv).requires_grad_(True)
+    normal = torch.zeros_like(m)
+    scales = torch.ones_like(m)
+    rots = torch.zeros(len(means), 4, device=DEV)
+    idxmap, colmap, depthmap, featuremap = r2.GaussianRasterizer2(settings)(
+        m, normal, torch.zeros_like(m), f, shs=torch.zeros(len(means), 1, 3, device=DEV), scales=scales,
+        rotations=rots)
+    w = torch.tensor(np.random.RandomState(4).randn(H, W, 64).astype(np.float32), device=DEV)
+    (featuremap * w).sum().backward()
+    o = oracle.idxmap_forward(means, vm, pm, fv, campos, W, H)
+    want = oracle.idxmap_backward(len(means), o["idx"], w.cpu().numpy())
+    np.testing.assert_allclose(f.grad.cpu().numpy(), want, rtol=0, atol=1e-5)
+    assert m.grad is not None and not m.grad.any()
+    assert torch.equal(idxmap.cpu(), torch.tensor(o["idx"]))
+
+
+def test_idxmap_empty_scene_and_errors(r2):
+    e = torch.empty(0, device=DEV)
+    z3 = torch.zeros(0, 3, device=DEV)
+    eye4 = torch.eye(4, device=DEV)
+    n, idx, col, dep, feat = r2._C.get_idxmap2(e, z3, e, e, e, eye4, eye4, 0.3, 0.3, 8, 12, torch.zeros(0, 64, device=DEV),
+                                               e, torch.zeros(3, device=DEV), False)
+    assert n == 0 and idx.shape == (8, 12) and not idx.any() and feat.shape == (8, 12, 64) and not feat.any()
+    with pytest.raises(RuntimeError):
+        r2._C.get_idxmap2(e, torch.zeros(5, 3, device=DEV), e, e, e, eye4, eye4, 0.3, 0.3, 8, 12,
+                          torch.zeros(5, 32, device=DEV), e, torch.zeros(3, device=DEV), False)
+    with pytest.raises(RuntimeError):
+        r2._C.get_idxmap2(e, torch.zeros(5, 3), e, e, e, eye4, eye4, 0.3, 0.3, 8, 12, torch.zeros(5, 64), e,
+                          torch.zeros(3), False)
