@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--train-steps", type=int, default=None,
                     help="full training iterations (render + L1/D-SSIM loss + backward + exchange + Adam) timed in a "
                          "second loop for the train iters/s figure; default: --steps, 0 to skip")
+    ap.add_argument("--no-idxmap", action="store_true",
+                    help="skip the third loop (index-map operator of the reference's second rasterizer, forward+backward)")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
@@ -198,6 +200,45 @@ def main():
             t_train = float(t.item())
         train = (t_train, train_stages)
 
+    # ---- third loop: the index-map operator (nearest centre per pixel) on the same scene and view ----
+    idxmap = None
+    if not args.no_idxmap and rank == 0:
+        from neuralgaussiansplatting_amd.rasterizer2 import _C as r2c
+        fvec = torch.randn(P, r2c.NUM_FEATURES, generator=torch.Generator(device="cpu").manual_seed(99)).to(dev)
+        gfeat = torch.randn(H, W, r2c.NUM_FEATURES, generator=torch.Generator(device="cpu").manual_seed(98)).to(dev)
+        e0 = torch.empty(0, device=dev)
+
+        def idx_step():
+            o = r2c.get_idxmap2(e0, scene.means3D, e0, e0, e0, cam.world_view_transform, cam.full_proj_transform,
+                                tanx, tany, H, W, fvec, e0, cam.camera_center, False, count_entries=False)
+            r2c.get_idxmap_backward2(scene.means3D, H, W, cam.camera_center, o[1], gfeat, False,
+                                     viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform)
+            return o
+
+        for _ in range(max(args.warmup, 1)):
+            o = idx_step()
+        _C.profile_enable(not args.no_stage_timing)
+        _C.profile_read(reset=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            idx_step()
+        torch.cuda.synchronize(dev)
+        t_idx = time.perf_counter() - t0
+        st = _C.profile_read(reset=True)
+        _C.profile_enable(False)
+        hit = int((o[1] >= 0).sum())
+        nb = {"idxmap_forward": 12 * P + 16 * W * H + 276 * W * H + 168 * hit,
+              "idxmap_backward": 256 * P + 164 * W * H + 312 * hit}
+        idxmap = {"ms_per_step": round(t_idx / args.steps * 1e3, 4),
+                  "Mpixels_per_s": round(W * H * args.steps / t_idx / 1e6, 1), "pixels_hit": hit,
+                  "what": "get_idxmap2 + get_idxmap_backward2, %d Gaussians with 64 features, %dx%d" % (P, W, H),
+                  "stages": {k: {"ms": round(tot / cnt, 4), "algorithmic_GB": round(nb[k] / 1e9, 4),
+                                 "GB_per_s": round(nb[k] / (tot / cnt * 1e-3) / 1e9, 1)}
+                             for k, (tot, cnt) in st.items() if cnt and k in nb}}
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * W * H * args.steps / elapsed / 1e6
@@ -264,7 +305,7 @@ def main():
                        "instances_per_tile_max": int(per_tile.max()),
                        "last_contributor_per_pixel_mean": round(float(stt["n_contrib"].mean()), 1),
                        "parallelism": "view-sharded dp%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "stages": stage_out, "train": train_out,
+            "roofline": roofline, "cpu_baseline": cpu, "stages": stage_out, "train": train_out, "idxmap": idxmap,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -162,8 +162,10 @@ int ngs_adam_step_activated(int P, float* const raw[3], const float* const grad[
  *
  * ngs_idxmap_backward = getidxmap_backward (rasterizer.h:87-96, rasterizer_impl.cu:986-1007):
  * dL_dfeature_vector[g][25..63] = sum over the pixels showing g of dL_dout_feature[pixel][25..63]; the whole
- * [P][64] output is written.  The reference adds without atomics from concurrent threads; here the sum is exact up
- * to float addition order.
+ * [P][64] output is written.  The reference adds without atomics from concurrent threads; here the sum is well
+ * defined.  viewmatrix / projmatrix are an addition to the reference's list and may be NULL: with them (and
+ * means3D) each Gaussian gathers the pixels of its own square in pixel order, without atomics; without them the
+ * pixels scatter with float atomics (sum exact up to addition order).
  */
 size_t ngs_idxmap_workspace_bytes(int width, int height);
 int ngs_idxmap_forward(int P, int M, int width, int height, const float* means3D, const float* normal,
@@ -172,7 +174,8 @@ int ngs_idxmap_forward(int P, int M, int width, int height, const float* means3D
                        const float* campos, int* out_idx, float* out_color, float* out_depth, float* out_feature,
                        int* radii, char* workspace, int debug, void* stream, int* num_rendered);
 int ngs_idxmap_backward(int P, int width, int height, const float* means3D, const float* campos, const int* out_idx,
-                        const float* dL_dout_feature, float* dL_dfeature_vector, int debug, void* stream);
+                        const float* dL_dout_feature, float* dL_dfeature_vector, const float* viewmatrix,
+                        const float* projmatrix, int debug, void* stream);
 
 /*
  * Introspection for parity tests: byte offsets (relative to the 256-byte

@@ -562,11 +562,11 @@ extern "C" int ngs_idxmap_forward(int P, int M, int width, int height, const flo
 
 extern "C" int ngs_idxmap_backward(int P, int width, int height, const float* means3D, const float* campos,
                                    const int* out_idx, const float* dL_dout_feature, float* dL_dfeature_vector,
-                                   int debug, void* stream)
+                                   const float* viewmatrix, const float* projmatrix, int debug, void* stream)
 {
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
-    (void)means3D; (void)campos;  // unused by the reference as well (rasterizer_impl.cu:820-847)
+    (void)campos;  // unused by the reference as well (rasterizer_impl.cu:820-847)
     if (P < 0 || width <= 0 || height <= 0) return fail("ngs_idxmap_backward", "bad sizes");
     if (P == 0) return 0;
     if (!out_idx || !dL_dout_feature || !dL_dfeature_vector) return fail("ngs_idxmap_backward", "missing required pointer");
@@ -574,8 +574,9 @@ extern "C" int ngs_idxmap_backward(int P, int width, int height, const float* me
         return fail("ngs_idxmap_backward", "feature arrays must be 16-byte aligned");
     const int ps = prof_acquire();
     prof_begin(ps, ST_IDXMAP_BWD, st);
-    NGS_HIP(hipMemsetAsync(dL_dfeature_vector, 0, (size_t)P * 64 * sizeof(float), st));
-    ngs_launch_idxmap_backward(st, P, width, height, out_idx, dL_dout_feature, dL_dfeature_vector);
+    const bool gather = means3D && viewmatrix && projmatrix;
+    ngs_launch_idxmap_backward(st, P, width, height, gather ? means3D : nullptr, viewmatrix, projmatrix, out_idx,
+                               dL_dout_feature, dL_dfeature_vector);
     prof_end(ps, ST_IDXMAP_BWD, st);
     NGS_STAGE("index map backward");
     return 0;

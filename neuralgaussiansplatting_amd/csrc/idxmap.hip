@@ -19,7 +19,36 @@
 // r2/cuda_rasterizer/auxiliary.h:38-41 (double arithmetic, rounded once to float)
 __device__ __forceinline__ float idx_ndc_to_pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
-// Per-Gaussian stage (r2/cuda_rasterizer/raster.cu:10-66) fused with the "key emission": one lane per Gaussian.
+// Per-Gaussian stage (r2/cuda_rasterizer/raster.cu:10-66): is the centre in front of the near plane and inside the
+// image, and which pixel square [x0,x1) x [y0,y1) does it cover.
+struct IdxSquare {
+    int visible, x0, y0, x1, y1;
+    float depth;
+};
+
+__device__ __forceinline__ IdxSquare idx_square(float px, float py, float pz, const float* __restrict__ view,
+                                                const float* __restrict__ proj, int W, int H)
+{
+    IdxSquare q = {0, 0, 0, 0, 0, 0.0f};
+    const float4 ph = xform44(px, py, pz, proj);
+    const float pw = 1.0f / (ph.w + 0.0000001f);
+    const float projx = ph.x * pw, projy = ph.y * pw;
+    const float3 pv = xform43(px, py, pz, view);
+    if (pv.z > 0.2f) {
+        const float fx = idx_ndc_to_pix(projx, W), fy = idx_ndc_to_pix(projy, H);
+        const int cx = (int)fx, cy = (int)fy;  // v_cvt_i32_f32: truncates like the reference's conversion
+        const float rad = 3.0f / pv.z;         // raster.cu:46,85
+        q.x0 = (int)fmaxf(0.0f, fx - rad);
+        q.y0 = (int)fmaxf(0.0f, fy - rad);
+        q.x1 = (int)fminf((float)W, fx + rad + 1.0f);
+        q.y1 = (int)fminf((float)H, fy + rad + 1.0f);
+        q.depth = pv.z;
+        q.visible = !(cx < 0 || cx >= W || cy < 0 || cy >= H);
+    }
+    return q;
+}
+
+// The per-Gaussian stage fused with the "key emission": one lane per Gaussian.
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void idxmap_splat_kernel(int P, int W, int H,
                                                                       const float* __restrict__ means,
                                                                       const float* __restrict__ view,
@@ -31,38 +60,28 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void idxmap_splat_kernel(int P, in
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
     uint32_t touched = 0;
     if (idx < P) {
-        int visible = 0;
-        const float px = means[3 * idx], py = means[3 * idx + 1], pz = means[3 * idx + 2];
-        const float4 ph = xform44(px, py, pz, proj);
-        const float pw = 1.0f / (ph.w + 0.0000001f);
-        const float projx = ph.x * pw, projy = ph.y * pw;
-        const float3 pv = xform43(px, py, pz, view);
-        if (pv.z > 0.2f) {
-            const float fx = idx_ndc_to_pix(projx, W), fy = idx_ndc_to_pix(projy, H);
-            const int cx = (int)fx, cy = (int)fy;  // v_cvt_i32_f32: truncates like the reference's conversion
-            const float rad = 3.0f / pv.z;         // raster.cu:46,85
-            const int x0 = (int)fmaxf(0.0f, fx - rad), y0 = (int)fmaxf(0.0f, fy - rad);
-            const int x1 = (int)fminf((float)W, fx + rad + 1.0f), y1 = (int)fminf((float)H, fy + rad + 1.0f);
-            if (!(cx < 0 || cx >= W || cy < 0 || cy >= H)) {
-                visible = 1;
-                touched = (uint32_t)((x1 - x0) * (y1 - y0));
-                const unsigned long long key = ((unsigned long long)__float_as_uint(pv.z) << 32) | (uint32_t)idx;
-                for (int y = y0; y < y1; y++)
-                    for (int x = x0; x < x1; x++) {
-                        unsigned long long* cell = zbuf + (size_t)y * W + x;
-                        // values only ever decrease, so a cell already below the key can be skipped unlocked
-                        if (key < *(volatile unsigned long long*)cell) atomicMin(cell, key);
-                    }
-            }
+        const IdxSquare q = idx_square(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2], view, proj, W, H);
+        if (q.visible) {
+            touched = (uint32_t)((q.x1 - q.x0) * (q.y1 - q.y0));
+            const unsigned long long key = ((unsigned long long)__float_as_uint(q.depth) << 32) | (uint32_t)idx;
+            for (int y = q.y0; y < q.y1; y++)
+                for (int x = q.x0; x < q.x1; x++) {
+                    unsigned long long* cell = zbuf + (size_t)y * W + x;
+                    // values only ever decrease, so a cell already below the key can be skipped unlocked
+                    if (key < *(volatile unsigned long long*)cell) atomicMin(cell, key);
+                }
         }
-        if (radii) radii[idx] = visible;
+        if (radii) radii[idx] = q.visible;
     }
     const uint32_t ws = wave_sum_u32(touched);
     if ((threadIdx.x & 63) == 0 && ws) atomicAdd(counter, ws);
 }
 
-// 16 lanes per pixel, lane c owning floats 4c..4c+3 of the pixel's 64-float feature row: every output row leaves
-// as one coalesced 256-byte run.  Writes every element of every output (zeros where no centre landed).
+// 16 lanes per pixel share the pixel's 64-float feature row so that it leaves as one contiguous 256-byte run, and
+// the work is spread evenly: lanes 0..11 each evaluate ONE sine/cosine pair of the positional encoding (the
+// expensive part), lanes 7..15 each copy one 16-byte group of the winner's features 28..63, lane 6 copies features
+// 25..27 and lane 15 writes the per-pixel scalars.  Every element of every output is written (zeros where no centre
+// landed).
 __global__ __launch_bounds__(256) void idxmap_resolve_kernel(int W, int H, const unsigned long long* __restrict__ zbuf,
                                                              const float* __restrict__ means,
                                                              const float* __restrict__ campos,
@@ -76,50 +95,45 @@ __global__ __launch_bounds__(256) void idxmap_resolve_kernel(int W, int H, const
     const int c = (int)(t & 15);
     if (pix >= (size_t)W * H) return;
     const unsigned long long cell = zbuf[pix];
-    float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float* row = out_feature + pix * IDX_FEATURES;
     if (cell == ~0ull) {
-        if (c == 0) {
+        *(float4*)(row + 4 * c) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (c == 15) {
             out_idx[pix] = -1;
             out_color[3 * pix] = 0.0f; out_color[3 * pix + 1] = 0.0f; out_color[3 * pix + 2] = 0.0f;
             out_depth[pix] = 0.0f;
         }
-    } else {
-        const uint32_t g = (uint32_t)cell;
-        const float depth = __uint_as_float((uint32_t)(cell >> 32));
-        // view direction of the winner (rasterizer_impl.cu:768-771)
-        float3 d = make_float3(means[3 * (size_t)g] - campos[0], means[3 * (size_t)g + 1] - campos[1],
-                               means[3 * (size_t)g + 2] - campos[2]);
-        const float len = sqrtf(f3_dot(d, d));
-        d = make_float3(d.x / len, d.y / len, d.z / len);
-        if (c == 0) {
-            out_idx[pix] = (int)g;
-            out_color[3 * pix] = d.x; out_color[3 * pix + 1] = d.y; out_color[3 * pix + 2] = d.z;
-            out_depth[pix] = depth;
-        }
-        const float* fv = feature_vector + (size_t)g * IDX_FEATURES;
-        if (c >= 7) {
-            out = *(const float4*)(fv + 4 * c);
-        } else {
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int e = 4 * c + k;
-                if (e == 0) {
-                    v[k] = depth;
-                } else if (e < IDX_FIRST_COPIED) {
-                    // positional encoding (rasterizer_impl.cu:26-42): element 1 + dim*8 + freq*2 (+1 for the cosine)
-                    const int p = e - 1, dim = p >> 3, fr = (p & 7) >> 1;
-                    const float x = dim == 0 ? d.x : dim == 1 ? d.y : d.z;
-                    const float arg = (float)(1 << fr) * IDX_PI * x;
-                    v[k] = (p & 1) ? cosf(arg) : sinf(arg);
-                } else {
-                    v[k] = fv[e];
-                }
-            }
-            out = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        return;
     }
-    *(float4*)(out_feature + pix * IDX_FEATURES + 4 * c) = out;
+    const uint32_t g = (uint32_t)cell;
+    const float depth = __uint_as_float((uint32_t)(cell >> 32));
+    // view direction of the winner (rasterizer_impl.cu:768-771)
+    float3 d = make_float3(means[3 * (size_t)g] - campos[0], means[3 * (size_t)g + 1] - campos[1],
+                           means[3 * (size_t)g + 2] - campos[2]);
+    const float len = sqrtf(f3_dot(d, d));
+    d = make_float3(d.x / len, d.y / len, d.z / len);
+    const float* fv = feature_vector + (size_t)g * IDX_FEATURES;
+    if (c < 3 * IDX_FREQS) {
+        // positional encoding (rasterizer_impl.cu:26-42): pair (dim, freq) -> elements 1 + dim*8 + freq*2, +1
+        const int dim = c >> 2, fr = c & 3;
+        const float x = dim == 0 ? d.x : dim == 1 ? d.y : d.z;
+        const float arg = (float)(1 << fr) * IDX_PI * x;
+        float sn, cs;
+        sincosf(arg, &sn, &cs);
+        row[1 + 2 * c] = sn;
+        row[2 + 2 * c] = cs;
+    }
+    if (c >= 7) {
+        *(float4*)(row + 4 * c) = *(const float4*)(fv + 4 * c);
+    } else if (c == 6) {
+        row[25] = fv[25]; row[26] = fv[26]; row[27] = fv[27];
+    }
+    if (c == 15) {
+        row[0] = depth;
+        out_idx[pix] = (int)g;
+        out_color[3 * pix] = d.x; out_color[3 * pix + 1] = d.y; out_color[3 * pix + 2] = d.z;
+        out_depth[pix] = depth;
+    }
 }
 
 // Backward (rasterizer_impl.cu:820-847): the gradient of feature-map elements 25..63 of every pixel flows to the
@@ -143,6 +157,38 @@ __global__ __launch_bounds__(256) void idxmap_backward_kernel(int P, int W, int 
     atomicAdd(dst + 3, v.w);
 }
 
+// The same sum as a gather, for callers that can supply the camera matrices: 16 lanes per Gaussian rebuild its
+// square, visit its pixels in row-major order and add the rows of the pixels that show it.  No atomics, the
+// additions happen in pixel order (the order of a sequential loop over the image), and every element of the
+// Gaussian's output row is written, zeros included.
+__global__ __launch_bounds__(256) void idxmap_backward_gather_kernel(int P, int W, int H,
+                                                                     const float* __restrict__ means,
+                                                                     const float* __restrict__ view,
+                                                                     const float* __restrict__ proj,
+                                                                     const int* __restrict__ out_idx,
+                                                                     const float* __restrict__ dL_dfeature,
+                                                                     float* __restrict__ dL_dfeature_vector)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t g = t >> 4;
+    const int c = (int)(t & 15);
+    if (g >= (size_t)P) return;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const IdxSquare q = idx_square(means[3 * g], means[3 * g + 1], means[3 * g + 2], view, proj, W, H);
+    if (q.visible && c >= IDX_FIRST_COPIED / 4) {
+        for (int y = q.y0; y < q.y1; y++)
+            for (int x = q.x0; x < q.x1; x++) {
+                const size_t pix = (size_t)y * W + x;
+                if (out_idx[pix] == (int)g) {
+                    const float4 v = *(const float4*)(dL_dfeature + pix * IDX_FEATURES + 4 * c);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            }
+        if (4 * c < IDX_FIRST_COPIED) acc.x = 0.0f;  // element 24 belongs to the positional encoding
+    }
+    stream_store4(dL_dfeature_vector + g * IDX_FEATURES + 4 * c, acc);
+}
+
 size_t ngs_idxmap_workspace_size(int W, int H) { return (size_t)W * H * 8 + 256; }
 
 void ngs_launch_idxmap_forward(hipStream_t s, int P, int W, int H, const float* means, const float* view,
@@ -161,9 +207,17 @@ void ngs_launch_idxmap_forward(hipStream_t s, int P, int W, int H, const float* 
                        means, campos, feature_vector, out_idx, out_color, out_depth, out_feature);
 }
 
-void ngs_launch_idxmap_backward(hipStream_t s, int P, int W, int H, const int* out_idx, const float* dL_dfeature,
+void ngs_launch_idxmap_backward(hipStream_t s, int P, int W, int H, const float* means, const float* view,
+                                const float* proj, const int* out_idx, const float* dL_dfeature,
                                 float* dL_dfeature_vector)
 {
+    if (means && view && proj) {
+        const size_t lanes = (size_t)P * 16;
+        hipLaunchKernelGGL(idxmap_backward_gather_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, P, W,
+                           H, means, view, proj, out_idx, dL_dfeature, dL_dfeature_vector);
+        return;
+    }
+    (void)hipMemsetAsync(dL_dfeature_vector, 0, (size_t)P * IDX_FEATURES * sizeof(float), s);
     const size_t threads = (size_t)W * H * 16;
     hipLaunchKernelGGL(idxmap_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P, W, H,
                        out_idx, dL_dfeature, dL_dfeature_vector);

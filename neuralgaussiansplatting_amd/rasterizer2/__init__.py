@@ -37,7 +37,8 @@ class _GetIdxMap2(torch.autograd.Function):
         # only the feature vector receives a gradient (rasterizer2/__init__.py:109-137); the others get zeros
         grad_feature_vector = _C.get_idxmap_backward2(
             means3D, raster_settings.image_height, raster_settings.image_width, raster_settings.campos, idxmap,
-            grad_featuremap.contiguous(), raster_settings.debug)[0]
+            grad_featuremap.contiguous(), raster_settings.debug, viewmatrix=raster_settings.viewmatrix,
+            projmatrix=raster_settings.projmatrix)[0]
         zeros = lambda t: torch.zeros_like(t) if t is not None else None
         return (zeros(means3D), zeros(normal), torch.zeros_like(means3D), grad_feature_vector, zeros(sh),
                 zeros(scales), zeros(rotations), None)

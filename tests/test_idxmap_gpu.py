@@ -74,12 +74,17 @@ def test_idxmap_backward_matches_oracle(r2, oracle):
     o = oracle.idxmap_forward(means, vm, pm, fv, campos, W, H)
     g = np.random.RandomState(3).randn(H, W, 64).astype(np.float32)
     want = oracle.idxmap_backward(len(means), o["idx"], g)
-    got = r2._C.get_idxmap_backward2(torch.tensor(means, device=DEV), H, W, torch.tensor(campos, device=DEV),
-                                     torch.tensor(o["idx"], device=DEV), torch.tensor(g, device=DEV), False)[0]
-    got = got.cpu().numpy()
+    args = (torch.tensor(means, device=DEV), H, W, torch.tensor(campos, device=DEV), torch.tensor(o["idx"], device=DEV),
+            torch.tensor(g, device=DEV), False)
+    # the reference's argument list: pixels scatter with float atomics, the sum is exact up to addition order
+    got = r2._C.get_idxmap_backward2(*args)[0].cpu().numpy()
     assert not got[:, :25].any()
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
     assert np.abs(want).max() > 1.0
+    # with the camera matrices each Gaussian gathers its pixels in pixel order: the checker's sum, bit for bit
+    got2 = r2._C.get_idxmap_backward2(*args, viewmatrix=torch.tensor(vm, device=DEV),
+                                      projmatrix=torch.tensor(pm, device=DEV))[0].cpu().numpy()
+    np.testing.assert_array_equal(got2, want)
 
 
 def test_idxmap_autograd_entry_point(r2, oracle):
