@@ -548,13 +548,15 @@ extern "C" int ngs_idxmap_forward(int P, int M, int width, int height, const flo
     const int ps = prof_acquire();
     prof_begin(ps, ST_IDXMAP_FWD, st);
     ngs_launch_idxmap_forward(st, P, width, height, means3D, viewmatrix, projmatrix, campos, feature_vector, workspace,
-                              out_idx, out_color, out_depth, out_feature, radii);
+                              out_idx, out_color, out_depth, out_feature, radii, num_rendered != nullptr);
     prof_end(ps, ST_IDXMAP_FWD, st);
     NGS_STAGE("index map");
     if (num_rendered) {  // only a caller that wants the entry count pays for the synchronisation
-        uint32_t n = 0;
-        NGS_HIP(hipMemcpyAsync(&n, workspace + (size_t)width * height * 8, sizeof n, hipMemcpyDeviceToHost, st));
+        uint32_t part[64];
+        NGS_HIP(hipMemcpyAsync(part, workspace + (size_t)width * height * 8, sizeof part, hipMemcpyDeviceToHost, st));
         NGS_HIP(hipStreamSynchronize(st));
+        uint32_t n = 0;
+        for (int i = 0; i < 64; i++) n += part[i];
         *num_rendered = (int)n;
     }
     return 0;

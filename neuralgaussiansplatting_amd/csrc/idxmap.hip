@@ -73,8 +73,12 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void idxmap_splat_kernel(int P, in
         }
         if (radii) radii[idx] = q.visible;
     }
-    const uint32_t ws = wave_sum_u32(touched);
-    if ((threadIdx.x & 63) == 0 && ws) atomicAdd(counter, ws);
+    // Entry count (the reference's return value), only for a caller that asks: 64 counters share the additions,
+    // since tens of thousands of waves adding to one address serialise at the memory side.
+    if (counter) {
+        const uint32_t ws = wave_sum_u32(touched);
+        if ((threadIdx.x & 63) == 0 && ws) atomicAdd(counter + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), ws);
+    }
 }
 
 // 16 lanes per pixel share the pixel's 64-float feature row so that it leaves as one contiguous 256-byte run, and
@@ -193,12 +197,13 @@ size_t ngs_idxmap_workspace_size(int W, int H) { return (size_t)W * H * 8 + 256;
 
 void ngs_launch_idxmap_forward(hipStream_t s, int P, int W, int H, const float* means, const float* view,
                                const float* proj, const float* campos, const float* feature_vector, char* workspace,
-                               int* out_idx, float* out_color, float* out_depth, float* out_feature, int* radii)
+                               int* out_idx, float* out_color, float* out_depth, float* out_feature, int* radii,
+                               bool count_entries)
 {
     unsigned long long* zbuf = (unsigned long long*)workspace;
-    uint32_t* counter = (uint32_t*)(workspace + (size_t)W * H * 8);
+    uint32_t* counter = count_entries ? (uint32_t*)(workspace + (size_t)W * H * 8) : nullptr;  // 64 partial counts
     (void)hipMemsetAsync(zbuf, 0xFF, (size_t)W * H * 8, s);
-    (void)hipMemsetAsync(counter, 0, 256, s);
+    if (counter) (void)hipMemsetAsync(counter, 0, 256, s);
     if (P > 0)
         hipLaunchKernelGGL(idxmap_splat_kernel, dim3((P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK),
                            dim3(NGS_GAUSS_BLOCK), 0, s, P, W, H, means, view, proj, zbuf, radii, counter);

@@ -184,7 +184,8 @@ void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const 
 size_t ngs_idxmap_workspace_size(int W, int H);
 void ngs_launch_idxmap_forward(hipStream_t s, int P, int W, int H, const float* means, const float* view,
                                const float* proj, const float* campos, const float* feature_vector, char* workspace,
-                               int* out_idx, float* out_color, float* out_depth, float* out_feature, int* radii);
+                               int* out_idx, float* out_color, float* out_depth, float* out_feature, int* radii,
+                               bool count_entries);
 // means/view/proj all non-NULL: gather per Gaussian (no atomics); otherwise scatter with float atomics.
 void ngs_launch_idxmap_backward(hipStream_t s, int P, int W, int H, const float* means, const float* view,
                                 const float* proj, const int* out_idx, const float* dL_dfeature,
