@@ -126,3 +126,28 @@ def test_idxmap_empty_scene_and_errors(r2):
     with pytest.raises(RuntimeError):
         r2._C.get_idxmap2(e, torch.zeros(5, 3), e, e, e, eye4, eye4, 0.3, 0.3, 8, 12, torch.zeros(5, 64), e,
                           torch.zeros(3), False)
+
+
+def test_idxmap_full_size_3m_1080p(r2, oracle):
+    """The benchmark's scene and view (3 M Gaussians, 1920x1080) at full size: the z-buffer formulation must pick
+    the same winner in every pixel as the checker's sort of all ~18 M (pixel, depth) entries."""
+    from neuralgaussiansplatting_amd import synthetic
+    sc, W, H = synthetic.make_config("c4", seed=1234)
+    cam = synthetic.make_view(W, H, 0)
+    means, vm, pm = sc.means3D.numpy(), cam.world_view_transform.numpy(), cam.full_proj_transform.numpy()
+    campos = cam.camera_center.numpy()
+    fv = np.random.RandomState(1).randn(len(means), 64).astype(np.float32)
+    o = oracle.idxmap_forward(means, vm, pm, fv, campos, W, H)
+    n, idx, col, dep, feat = run_hip(r2, means, vm, pm, fv, campos, W, H)
+    assert n == o["num_rendered"] > 10_000_000
+    np.testing.assert_array_equal(idx.cpu().numpy(), o["idx"])
+    np.testing.assert_array_equal(dep.cpu().numpy().view(np.uint32), o["depth"].view(np.uint32))
+    f = feat.cpu().numpy()
+    np.testing.assert_array_equal(f[..., 25:], o["feature"][..., 25:])
+    np.testing.assert_allclose(f[..., 1:25], o["feature"][..., 1:25], rtol=0, atol=2e-6)
+    g = np.random.RandomState(2).randn(H, W, 64).astype(np.float32)
+    want = oracle.idxmap_backward(len(means), o["idx"], g)
+    got = r2._C.get_idxmap_backward2(torch.tensor(means, device=DEV), H, W, torch.tensor(campos, device=DEV), idx,
+                                     torch.tensor(g, device=DEV), False, viewmatrix=torch.tensor(vm, device=DEV),
+                                     projmatrix=torch.tensor(pm, device=DEV))[0].cpu().numpy()
+    np.testing.assert_array_equal(got, want)

@@ -197,6 +197,44 @@ def test_config2_100k_800x800(dgr, oracle):
         oracle.set_threads(1)
 
 
+def test_config4_3m_1080p_full_size(dgr, oracle):
+    """The headline configuration (3 M Gaussians, 1920x1080, SH degree 3) at full size: per-Gaussian integers,
+    sorted keys, lists and ranges bit-exact, image and gradients within the bar, plus properties that do not need
+    the checker (the sorted list is sorted, the ranges partition it, the backward pass is linear in dL/dpixel)."""
+    import os
+    from neuralgaussiansplatting_amd import synthetic
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        sc, W, H = synthetic.make_config("c4", seed=1234)
+        cam = synthetic.make_view(W, H, 0)
+        c = dict(scene=sc, cam=cam, W=W, H=H, D=3, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
+                 tanfovy=math.tan(cam.FoVy * 0.5))
+        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(8))
+        o = oracle_forward(oracle, c)
+        h = run_hip(dgr, c, dL_dpix=dL)
+        assert h["R"] == o["num_rendered"] > 8_000_000
+        check_forward(o, h, exact_pixels=False)
+        # properties of the binning state on their own
+        keys = h["keys_sorted"]
+        assert (keys[1:] >= keys[:-1]).all()
+        rng = h["ranges"].astype(np.int64)
+        nonempty = rng[:, 1] > rng[:, 0]
+        assert (rng[nonempty, 0][1:] == rng[nonempty, 1][:-1]).all()  # consecutive, no gaps, no overlap
+        assert rng[nonempty, 0][0] == 0 and rng[nonempty, 1][-1] == h["R"]
+        assert int(h["tiles_touched"].sum()) == h["R"]
+        og = oracle_backward(oracle, c, o, dL)
+        check_grads(h["grads"], og, scale=float(W * H))
+        # linearity in dL/dpixel (float atomics reorder sums: tolerance, not equality)
+        h2 = run_hip(dgr, c, dL_dpix=2.0 * dL)
+        for name in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations"):
+            a, b = h["grads"][name], h2["grads"][name]
+            assert float(np.abs(b - 2.0 * a).max()) <= 1e-4 * float(np.abs(b).max()), name
+        # the forward pass is deterministic
+        assert np.array_equal(h["color"], h2["color"]) and np.array_equal(h["point_list"], h2["point_list"])
+    finally:
+        oracle.set_threads(1)
+
+
 def test_empty_scene(dgr):
     dev = torch.device("cuda:0")
     e = torch.empty(0)
