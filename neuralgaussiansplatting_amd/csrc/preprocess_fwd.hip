@@ -55,9 +55,24 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     uint32_t* __restrict__ block_sums, uint32_t* __restrict__ misc)
 {
     __shared__ uint32_t wave_tot[NGS_GAUSS_BLOCK / 64];
+    __shared__ float s_sh[EAGER ? NGS_GAUSS_BLOCK * 52 : 1];
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
     uint32_t my_tiles = 0;
     int my_radius = 0;
+    if (EAGER) {
+        // Each wave moves its 64 SH rows (12 KiB, contiguous in memory) into LDS with coalesced streaming loads:
+        // a lane reading its own 192-byte row would make every load instruction touch 64 different cache lines.
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wave_first = blockIdx.x * NGS_GAUSS_BLOCK + wave * 64;
+        float* const wrows = s_sh + wave * 64 * 52;
+#pragma unroll
+        for (int t = 0; t < 12; t++) {
+            const int f = t * 64 + lane, g = f / 12, c = f - g * 12;
+            if (wave_first + g < P) *(float4*)(wrows + g * 52 + c * 4) = stream_load4(shs + (size_t)(wave_first + g) * 48 + 4 * c);
+        }
+        // rows are written and read by the same wave only: no workgroup barrier needed, LDS operations of a wave
+        // complete in order
+    }
     if (idx < P) {
         const float px = means[3 * idx], py = means[3 * idx + 1], pz = means[3 * idx + 2];
         float4 e_sh[EAGER ? 12 : 1];
@@ -67,11 +82,6 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
             e_q = ((const float4*)rots)[idx];
             e_s0 = scales[3 * idx]; e_s1 = scales[3 * idx + 1]; e_s2 = scales[3 * idx + 2];
             e_op = opac[idx];
-            // plain (cached) loads: a lane reads its 192-byte row 16 bytes at a time and relies on the cache for
-            // the rest of each line
-            const float4* row = (const float4*)(shs + (size_t)48 * idx);
-#pragma unroll
-            for (int k = 0; k < 12; k++) e_sh[k] = row[k];
         }
         const float3 pv = xform43(px, py, pz, view);
         if (pv.z <= 0.2f) {
@@ -117,6 +127,9 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
                         float3 d = make_float3(px - campos[0], py - campos[1], pz - campos[2]);
                         const float len = sqrtf(f3_dot(d, d));
                         d = make_float3(d.x / len, d.y / len, d.z / len);
+                        const float* my_row = s_sh + (threadIdx.x >> 6) * 64 * 52 + (threadIdx.x & 63) * 52;
+#pragma unroll
+                        for (int k = 0; k < 12; k++) e_sh[k] = *(const float4*)(my_row + 4 * k);
                         col = sh_to_rgb(3, (const float*)e_sh, d, cb);
                     } else if (col_pre) {
                         col = make_float3(col_pre[3 * (size_t)idx], col_pre[3 * (size_t)idx + 1],
@@ -127,10 +140,14 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
                         d = make_float3(d.x / len, d.y / len, d.z / len);
                         col = sh_to_rgb(D, shs + (size_t)3 * M * idx, d, cb);
                     }
-                    float4* r = rec + 4 * (size_t)idx;
+                    // EAGER: the record is parked in this lane's (now consumed) LDS row and leaves with the wave's
+                    // other records as coalesced 1-KiB stores below
+                    float4* r = EAGER ? (float4*)(s_sh + (threadIdx.x >> 6) * 64 * 52 + (threadIdx.x & 63) * 52)
+                                      : rec + 4 * (size_t)idx;
                     r[0] = make_float4(ix, iy, k.c * dinv, -k.b * dinv);
                     r[1] = make_float4(k.a * dinv, EAGER ? e_op : opac[idx], col.x, col.y);
                     r[2] = make_float4(col.z, 0.0f, 0.0f, 0.0f);
+                    if (EAGER) r[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     depth[idx] = pv.z;
                     rect[idx] = make_uint2(x0 | (x1 << 16), y0 | (y1 << 16));
                     clamped[idx] = (uint8_t)cb;
@@ -141,6 +158,19 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
         }
         radii[idx] = my_radius;
         tiles[idx] = my_tiles;
+    }
+    if (EAGER) {
+        // records of the wave's visible Gaussians: 4 KiB contiguous per wave (a culled Gaussian's record is never
+        // read, so its slot is simply skipped)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wave_first = blockIdx.x * NGS_GAUSS_BLOCK + wave * 64;
+        const float* const wrows = s_sh + wave * 64 * 52;
+        const unsigned long long vis = __ballot(my_tiles != 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int f = t * 64 + lane, g = f >> 2, c = f & 3;
+            if ((vis >> g) & 1ull) rec[4 * (size_t)(wave_first + g) + c] = *(const float4*)(wrows + g * 52 + c * 4);
+        }
     }
     // Tiles touched by this block of 256 Gaussians: the first level of the instance-offset scan.
     const uint32_t ws = wave_sum_u32(my_tiles);
