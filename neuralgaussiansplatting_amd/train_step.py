@@ -53,7 +53,11 @@ def inverse_sigmoid(x):
 
 
 class GaussianTrainer:
-    """Raw parameters, Adam state and the activated copies the rasterizer reads, all resident on one GPU."""
+    """Raw parameters, Adam state and the activated copies the rasterizer reads, all resident on one GPU.
+
+    With a process group, every rank steps its own view and the gradients are averaged over the ranks' views before
+    Adam, so all ranks hold identical parameters.  The densification statistics are this rank's views only: sum
+    ``xyz_gradient_accum`` / ``denom`` and max-reduce ``max_radii2D`` over the ranks before densifying."""
 
     def __init__(self, scene, device, opt=None, spatial_lr_scale=1.0, factored_exchange=True,
                  densify_stats=True):
