@@ -142,7 +142,15 @@ class FactoredGradientExchange:
         P = self.P
         _C.masked_color_gradient(aux["geom"], aux["dL_dcolors"], out=self.local[:3 * P])
         self.local[3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
-        if self.world > 1:
+        pending = None
+        if self.world > 1 and dist.get_backend(group) == "nccl":
+            # both collectives are queued at once; the SH rebuild below needs only the gather, so it runs while the
+            # all-reduce of the other gradients is still on the wire
+            gather = dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=group, async_op=True)
+            pending = dist.all_reduce(self.reduced, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            gather.wait()
+            gathered = self.gathered
+        elif self.world > 1:
             _all_gather_rows(self.gathered, self.local, group)
             _all_reduce_sum(self.reduced, group)
             gathered = self.gathered
@@ -150,6 +158,8 @@ class FactoredGradientExchange:
             gathered = self.local.view(1, self.row)
         _C.sh_gradient_from_views(scene.means3D, gathered[:, 3 * P:3 * P + 3], gathered[:, :3 * P], scene.sh_degree,
                                   self.M, out=self.dL_dsh)
+        if pending is not None:
+            pending.wait()
         return None
 
 
