@@ -143,7 +143,8 @@ class FactoredGradientExchange:
         _C.masked_color_gradient(aux["geom"], aux["dL_dcolors"], out=self.local[:3 * P])
         self.local[3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
         pending = None
-        if self.world > 1 and dist.get_backend(group) == "nccl":
+        grouped = dist.is_available() and dist.is_initialized()
+        if grouped and dist.get_backend(group) == "nccl":  # also with a single rank: same calls, trivial traffic
             # both collectives are queued at once; the SH rebuild below needs only the gather, so it runs while the
             # all-reduce of the other gradients is still on the wire
             gather = dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=group, async_op=True)

@@ -421,3 +421,48 @@ def test_view_factored_sh_gradient_equals_sum_of_per_view_gradients(D, M, P, dgr
     assert torch.equal(got, dense_sum)
     with pytest.raises(RuntimeError):
         dgr._C.sh_gradient_from_views(scene.means3D, rows[:, 3 * P:3 * P + 3], rows[:, :3 * P], 3, 9)
+
+
+def _rccl_single_rank_worker(rank, port, ret):
+    """Runs the factored exchange over a real RCCL communicator (one rank: the collectives carry no traffic, but the
+    calls, buffer shapes, stream waits and the rebuild kernel are the ones a multi-GPU run makes)."""
+    import os
+    import torch.distributed as dist
+    from neuralgaussiansplatting_amd import synthetic, view_parallel
+    from neuralgaussiansplatting_amd.cameras import make_camera
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        P, M, D, W, H = 2500, 16, 3, 96, 64
+        sc = synthetic.make_scene(P, D, (-3.5, -2.5), (1.3, 1.3, 1.3), seed=31, sh_coeffs=M).to(dev)
+        cam = make_camera(W, H, synthetic.FOVX, (0.7, 0.5, -4.0), device=dev)
+        tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+        bg = torch.zeros(3, device=dev)
+        ok = True
+        for cls in (view_parallel.FactoredGradientExchange, view_parallel.GradientBucket):
+            ex = cls(P, M, dev)
+            _, _, aux = view_parallel.forward_backward(sc, cam, bg, lambda c: dL, ex, tanx, tany)
+            ex.reduce(sc, cam, aux)
+            torch.cuda.synchronize()
+            dense = view_parallel.GradientBucket(P, M, dev)
+            view_parallel.forward_backward(sc, cam, bg, lambda c: dL, dense, tanx, tany)
+            torch.cuda.synchronize()
+            for name, want in dense.shaped().items():
+                got = ex.shaped()[name]
+                ok = ok and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-12
+        ret[0] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_factored_exchange_over_rccl_single_rank(dgr):
+    import os
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_single_rank_worker, args=(33500 + os.getpid() % 2000, ret), nprocs=1, join=True)
+    assert dict(ret) == {0: True}
