@@ -35,7 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
 def stage_bytes(P, R, W, H, D, M, vis, views=1):
-    """Algorithmic HBM bytes of one launch of each stage (per-unit figures in DESIGN.md)."""
+    """Algorithmic HBM bytes of one launch of each stage: every array a stage must read or write counted once,
+    intermediates that fused kernels never move already left out."""
     c = (D + 1) ** 2
     T = ((W + 15) // 16) * ((H + 15) // 16)
     tile_passes = (T.bit_length() + 7) // 8  # bit_length(T) is the reference's getHigherMsb(T)
