@@ -56,6 +56,10 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
         "sh_gradient_from_views": 25 * P + 12 * P + views * 12 * P + 12 * M * P,
         "l1_ssim_loss": 11 * 12 * W * H,
         "adam_identity_groups": 28 * (3 * P + 3 * M * P),
+        # per-Gaussian backward with the SH coefficients' Adam step fused in (single-rank training iterations):
+        # coefficients and both moments read and written once, no gradient rows
+        "preprocess_bwd_sh_adam": 4 * P + vP * 105 + 92 * P + 72 * M * P,
+        "adam_positions_only": 28 * 3 * P,
         "adam_activated_groups": 32 * 8 * P + 40 * P,
     }
 
@@ -279,16 +283,20 @@ def main():
         if train is not None:
             t_train, train_stages = train
             per_iter = {}
+            fused = world == 1 and M == 16
             for name, (tot, cnt) in train_stages.items():
                 if cnt:
                     ms = tot / train_steps
+                    bkey = {"preprocess_bwd": "preprocess_bwd_sh_adam", "adam_identity_groups": "adam_positions_only"
+                            }.get(name, name) if fused else name
                     per_iter[name] = {"ms_per_iter": round(ms, 4), "launches_per_iter": round(cnt / train_steps, 2),
-                                      "GB_per_s": round(nbytes[name] / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
+                                      "GB_per_s": round(nbytes[bkey] / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
             train_out = {"iters_per_s": round(world * train_steps / t_train, 2),
                          "ms_per_iter": round(t_train / train_steps * 1e3, 4), "steps": train_steps,
-                         "what": "lr schedule + render + fused L1/D-SSIM loss + backward + %sfused Adam with "
+                         "what": "lr schedule + render + fused L1/D-SSIM loss + backward%s + %sfused Adam with "
                                  "activations and densification statistics, fixed random target image"
-                                 % ("gradient exchange + " if world > 1 else ""),
+                                 % (" with the SH coefficients' Adam step inside" if fused else "",
+                                    "gradient exchange + " if world > 1 else ""),
                          "stages": per_iter}
         line = {
             "metric": "fwd+bwd Mpixels/s (rasterizer forward+backward, 1080p / 3M Gaussians per GPU)"

@@ -78,6 +78,27 @@ int ngs_rasterize_backward(int P, int D, int M, int R, const float* background, 
                            float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                            float* dL_dscale, float* dL_drot, int debug, void* stream);
 
+/*
+ * ngs_rasterize_backward with the optimiser step of the SH coefficients fused in.  No counterpart in the
+ * reference, where the coefficient gradient is written to memory (rasterize_points.cu:156) and torch.optim.Adam
+ * reads it back (scene/gaussian_model.py:262-263,275; train.py:124): here the gradient rows never leave the chip.
+ * Arguments as ngs_rasterize_backward, except: `shs` ([P][16][3]) is updated IN PLACE, there is no dL_dsh (and no
+ * colors_precomp), and sh_exp_avg / sh_exp_avg_sq are Adam's moments of the same shape.  lr_dc applies to
+ * coefficient 0 of every row, lr_rest to the others; constants and `step` as for ngs_adam_step.  Requires M == 16
+ * and 16-byte aligned arrays.  Single-view steps only: a caller that sums gradients over views must exchange them
+ * before the optimiser runs.
+ */
+int ngs_rasterize_backward_sh_adam(int P, int D, int M, int R, const float* background, int width, int height,
+                                   const float* means3D, float* shs, const float* scales, float scale_modifier,
+                                   const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                   const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                                   const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                   float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale,
+                                   float* dL_drot, float* sh_exp_avg, float* sh_exp_avg_sq, double lr_dc, double lr_rest,
+                                   double beta1, double beta2, double eps, int step, float grad_scale, int debug,
+                                   void* stream);
+
 /* Rasterizer::markVisible (rasterizer.h:24-29, rasterizer_impl.cu:141-153):
  * present[i] = 1 if Gaussian i passes the near-plane test, else 0 (bytes). */
 int ngs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -343,27 +343,26 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     return 0;
 }
 
-extern "C" int ngs_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,
-                                      const float* means3D, const float* shs, const float* colors_precomp,
-                                      const float* scales, float scale_modifier, const float* rotations,
-                                      const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                                      const float* campos, float tan_fovx, float tan_fovy, const int* radii,
-                                      char* geom_buffer, char* binning_buffer, char* image_buffer,
-                                      const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                      float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                                      float* dL_dscale, float* dL_drot, int debug, void* stream)
+static int backward_impl(const char* fn, int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                         float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                         float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                         const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                         float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                         float* dL_drot, int debug, void* stream, const ShAdamArgs* sh_adam)
 {
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
     (void)colors_precomp;
-    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail("ngs_rasterize_backward", "bad sizes");
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(fn, "bad sizes");
     if (P == 0) return 0;
-    if (!geom_buffer || !binning_buffer || !image_buffer) return fail("ngs_rasterize_backward", "missing state buffer");
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(fn, "missing state buffer");
     if (!means3D || !viewmatrix || !projmatrix || !background || !dL_dpix || !dL_dmean2D || !dL_dopacity ||
         !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
-        return fail("ngs_rasterize_backward", "missing required pointer");
-    if (shs && !campos) return fail("ngs_rasterize_backward", "shs given without campos");
-    if (!cov3D_precomp && (!scales || !rotations)) return fail("ngs_rasterize_backward", "need scales+rotations or cov3D_precomp");
+        return fail(fn, "missing required pointer");
+    if (shs && !campos) return fail(fn, "shs given without campos");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(fn, "need scales+rotations or cov3D_precomp");
     const NgsCamera cam = make_camera(width, height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos);
     const GeomLayout gl = ngs_geom_layout((size_t)P);
     const BinLayout bl = ngs_bin_layout((size_t)R);
@@ -391,10 +390,61 @@ extern "C" int ngs_rasterize_backward(int P, int D, int M, int R, const float* b
     ngs_launch_preprocess_bwd(st, P, D, M, means3D, radii, shs, (const uint8_t*)(gb + gl.clamped),
                               cov3D_precomp ? nullptr : scales, rotations, scale_modifier, cov3D_precomp, cam, acc,
                               dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                              dL_drot);
+                              dL_drot, sh_adam);
     prof_end(ps, ST_PREPROCESS_BWD, st);
     NGS_STAGE("preprocess backward");
     return 0;
+}
+
+extern "C" int ngs_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                                      const float* means3D, const float* shs, const float* colors_precomp,
+                                      const float* scales, float scale_modifier, const float* rotations,
+                                      const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                      const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                                      char* geom_buffer, char* binning_buffer, char* image_buffer,
+                                      const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                      float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                                      float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    return backward_impl("ngs_rasterize_backward", P, D, M, R, background, width, height, means3D, shs, colors_precomp,
+                         scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx,
+                         tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic,
+                         dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream,
+                         nullptr);
+}
+
+extern "C" int ngs_rasterize_backward_sh_adam(int P, int D, int M, int R, const float* background, int width,
+                                              int height, const float* means3D, float* shs, const float* scales,
+                                              float scale_modifier, const float* rotations,
+                                              const float* cov3D_precomp, const float* viewmatrix,
+                                              const float* projmatrix, const float* campos, float tan_fovx,
+                                              float tan_fovy, const int* radii, char* geom_buffer,
+                                              char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                                              float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale,
+                                              float* dL_drot, float* sh_exp_avg, float* sh_exp_avg_sq, double lr_dc,
+                                              double lr_rest, double beta1, double beta2, double eps, int step,
+                                              float grad_scale, int debug, void* stream)
+{
+    const char* fn = "ngs_rasterize_backward_sh_adam";
+    g_err[0] = 0;
+    if (!shs || !sh_exp_avg || !sh_exp_avg_sq) return fail(fn, "missing SH coefficients or optimiser state");
+    if (M != 16) return fail(fn, "the fused update needs rows of 16 coefficients");
+    if (((uintptr_t)shs | (uintptr_t)sh_exp_avg | (uintptr_t)sh_exp_avg_sq) % 16 != 0)
+        return fail(fn, "SH coefficients and optimiser state must be 16-byte aligned");
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0 && step >= 1))
+        return fail(fn, "bad Adam constants or step < 1");
+    ShAdamArgs a;
+    a.param = shs;
+    a.exp_avg = sh_exp_avg;
+    a.exp_avg_sq = sh_exp_avg_sq;
+    a.step_head = ngs_adam_step_size(lr_dc, beta1, step);
+    a.step_tail = ngs_adam_step_size(lr_rest, beta1, step);
+    a.k = ngs_adam_const(beta1, beta2, eps, step, grad_scale);
+    return backward_impl(fn, P, D, M, R, background, width, height, means3D, shs, nullptr, scales, scale_modifier,
+                         rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
+                         geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity,
+                         dL_dcolor, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot, debug, stream, &a);
 }
 
 extern "C" int ngs_masked_color_gradient(int P, const char* geom_buffer, const float* dL_dcolor, float* out,

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <math.h>
 #include <stdint.h>
 
 #define NGS_TILE_W 16
@@ -120,6 +121,42 @@ struct NgsCamera {
     int W, H, grid_x, grid_y;
 };
 
+// Adam (torch.optim.Adam's single-tensor update, no weight decay / amsgrad).  The scalars are formed on the host in
+// double and rounded to float once, as torch does with its Python floats: one_minus_beta1 = float(1 - beta1),
+// one_minus_beta2 = float(1 - beta2), bc2_sqrt = float(sqrt(1 - beta2^t)); a group's step is float(lr / (1 - beta1^t)).
+struct AdamConst {
+    float one_minus_beta1, beta2, one_minus_beta2, eps, bc2_sqrt, grad_scale;
+};
+
+static inline AdamConst ngs_adam_const(double beta1, double beta2, double eps, int step, float grad_scale)
+{
+    AdamConst k;
+    k.one_minus_beta1 = (float)(1.0 - beta1);
+    k.beta2 = (float)beta2;
+    k.one_minus_beta2 = (float)(1.0 - beta2);
+    k.eps = (float)eps;
+    k.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    k.grad_scale = grad_scale;
+    return k;
+}
+
+static inline float ngs_adam_step_size(double lr, double beta1, int step)
+{
+    return (float)(lr / (1.0 - pow(beta1, (double)step)));
+}
+
+// Optimiser state of the SH coefficients for the per-Gaussian backward kernel's fused update: with `param` set the
+// kernel applies Adam to the [P][16][3] coefficient rows in place instead of writing their gradient (the DC
+// coefficient uses step_head, the others step_tail: two parameter groups in the reference,
+// scene/gaussian_model.py:262-263).
+struct ShAdamArgs {
+    float* param;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float step_head, step_tail;
+    AdamConst k;
+};
+
 // ---------------------------------------------------------------------------
 // Stage launchers (each defined in the .hip file named in the comment).
 // ---------------------------------------------------------------------------
@@ -159,7 +196,8 @@ void ngs_launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* 
                                const float* shs, const uint8_t* clamped, const float* scales, const float* rots,
                                float mod, const float* cov_pre, const NgsCamera& cam, const float* acc,
                                float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
+                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                               const ShAdamArgs* sh_adam);
 
 // sh_views.hip: per-Gaussian colour gradient with the clamp mask applied, and the SH coefficient gradient summed
 // over V views from those masked colour gradients.
@@ -313,6 +351,14 @@ __device__ __forceinline__ float4 stream_load4(const float* p)
 __device__ __forceinline__ void stream_store4(float* p, float4 v)
 {
     __builtin_nontemporal_store((ngs_v4f){v.x, v.y, v.z, v.w}, (ngs_v4f*)p);
+}
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float step, const AdamConst& k)
+{
+    m = m + k.one_minus_beta1 * (g - m);
+    v = v * k.beta2 + k.one_minus_beta2 * g * g;
+    const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+    return p - step * (m / denom);
 }
 
 // Spherical-harmonics constants (cuda_rasterizer/auxiliary.h:22-39).

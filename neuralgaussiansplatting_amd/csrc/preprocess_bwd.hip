@@ -15,6 +15,7 @@
 // 52 floats: conflict-free 128-bit reads).
 // Built with -ffp-contract=off so the recomputed covariance equals the
 // forward's bit for bit.
+#include <string.h>
 #include "ngs_common.h"
 
 #define SH_ROW 48      // floats per Gaussian when M == 16
@@ -114,13 +115,13 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const 
 template <bool SH_LDS>
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
     int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii,
-    const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
-    const float* __restrict__ rots, float mod, const float* __restrict__ cov_pre, const NgsCamera cam,
+    const float* shs /* may alias adam.param */, const uint8_t* __restrict__ clamped,
+    const float* __restrict__ scales, const float* __restrict__ rots, float mod, const float* __restrict__ cov_pre, const NgsCamera cam,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
     const float* __restrict__ acc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
-    float* __restrict__ dL_drot)
+    float* __restrict__ dL_drot, const ShAdamArgs adam)
 {
     __shared__ float s_sh[SH_LDS ? NGS_GAUSS_BLOCK * SH_ROW_LDS : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         // ---- SH backward ----
         if (shs) {
             const float* sh_in = SH_LDS ? my_row : shs + (size_t)3 * M * i;
-            float* sh_out = !dL_dsh ? nullptr : SH_LDS ? my_row : dL_dsh + (size_t)3 * M * i;
+            float* sh_out = SH_LDS ? ((dL_dsh || adam.param) ? my_row : nullptr)
+                                   : (dL_dsh ? dL_dsh + (size_t)3 * M * i : nullptr);
             const float3 ds = sh_backward(D, M, make_float3(mx, my, mz), campos, sh_in, clamped[i], g_col, sh_out);
             dmean.x += ds.x; dmean.y += ds.y; dmean.z += ds.z;
         }
@@ -295,7 +297,32 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         }
     }
 
-    if (SH_LDS && dL_dsh) {
+    if (SH_LDS && adam.param) {
+        __syncthreads();
+        // Fused optimiser step: the gradient rows never leave the chip.  Each 16-byte group of the wave's 64 rows
+        // takes its gradient from LDS (zero for a culled Gaussian, whose moments still decay), its coefficient
+        // and Adam moments from memory, and writes all three back; coalesced and streamed like the gradient
+        // store it replaces.
+#pragma unroll
+        for (int t = 0; t < SH_ROW * 64 / 4 / 64; t++) {
+            const int f = t * 64 + lane, g = f / (SH_ROW / 4), c = f - g * (SH_ROW / 4);
+            if (wave_first + g < P) {
+                float4 gr = make_float4(0, 0, 0, 0);
+                if ((vis_mask >> g) & 1ull) gr = *(const float4*)(wrows + g * SH_ROW_LDS + c * 4);
+                const size_t o = (size_t)(wave_first + g) * SH_ROW + 4 * c;
+                float4 p = stream_load4(adam.param + o), m = stream_load4(adam.exp_avg + o),
+                       v = stream_load4(adam.exp_avg_sq + o);
+                const float s3 = c == 0 ? adam.step_head : adam.step_tail;  // elements 0..2 of a row are the DC term
+                p.x = adam_update(p.x, gr.x * adam.k.grad_scale, m.x, v.x, s3, adam.k);
+                p.y = adam_update(p.y, gr.y * adam.k.grad_scale, m.y, v.y, s3, adam.k);
+                p.z = adam_update(p.z, gr.z * adam.k.grad_scale, m.z, v.z, s3, adam.k);
+                p.w = adam_update(p.w, gr.w * adam.k.grad_scale, m.w, v.w, adam.step_tail, adam.k);
+                stream_store4(adam.param + o, p);
+                stream_store4(adam.exp_avg + o, m);
+                stream_store4(adam.exp_avg_sq + o, v);
+            }
+        }
+    } else if (SH_LDS && dL_dsh) {
         __syncthreads();
         // the wave's 64 gradient rows leave as 12 fully coalesced 1-KiB stores; culled Gaussians get zeros
 #pragma unroll
@@ -314,19 +341,23 @@ void ngs_launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* 
                                const float* shs, const uint8_t* clamped, const float* scales, const float* rots,
                                float mod, const float* cov_pre, const NgsCamera& cam, const float* acc,
                                float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot)
+                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                               const ShAdamArgs* sh_adam)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    ShAdamArgs adam;
+    memset(&adam, 0, sizeof adam);
+    if (sh_adam) adam = *sh_adam;  // the caller has checked that the LDS path below applies
     // LDS staging needs 16-byte aligned 192-byte rows
     const bool lds = shs && M == 16 && ((uintptr_t)shs % 16 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
     if (lds)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, radii,
                            shs, clamped, scales, rots, mod, cov_pre, cam, cam.view, cam.proj, cam.campos, acc,
                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                           dL_drot);
+                           dL_drot, adam);
     else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, radii,
                            shs, clamped, scales, rots, mod, cov_pre, cam, cam.view, cam.proj, cam.campos, acc,
                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                           dL_drot);
+                           dL_drot, adam);
 }

@@ -195,22 +195,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void ssim_l1_backward_kernel(
 // Adam.  Operation order of torch.optim.Adam's single-tensor path: exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v +
 // (1-b2)*g*g; denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom.
 // ---------------------------------------------------------------------------------------------------------------
-// The scalars are formed on the host in double and rounded to float once, as torch does with its Python floats:
-// one_minus_beta1 = float(1 - beta1), one_minus_beta2 = float(1 - beta2), bc2_sqrt = float(sqrt(1 - beta2^t)), and a
-// group's `step` below is float(lr / (1 - beta1^t)).
 typedef float v4f __attribute__((ext_vector_type(4)));
-
-struct AdamConst {
-    float one_minus_beta1, beta2, one_minus_beta2, eps, bc2_sqrt, grad_scale;
-};
-
-__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float step, const AdamConst& k)
-{
-    m = m + k.one_minus_beta1 * (g - m);
-    v = v * k.beta2 + k.one_minus_beta2 * g * g;
-    const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
-    return p - step * (m / denom);
-}
 
 // Flat tensor whose activation is the identity (positions, SH coefficients).  Elements whose index modulo `period`
 // is below `head` use lr_head, the others lr_tail (SH rows [P][M][3]: the DC coefficient and the higher bands are
@@ -376,27 +361,13 @@ void ngs_launch_l1_ssim(hipStream_t s, int W, int H, float lambda_dssim, const f
                        d_e1, d_e12, (1.0f - lambda_dssim) * inv_count, lambda_dssim * inv_count, dL_dimg);
 }
 
-static AdamConst adam_const(double beta1, double beta2, double eps, int step, float grad_scale)
-{
-    AdamConst k;
-    k.one_minus_beta1 = (float)(1.0 - beta1);
-    k.beta2 = (float)beta2;
-    k.one_minus_beta2 = (float)(1.0 - beta2);
-    k.eps = (float)eps;
-    k.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
-    k.grad_scale = grad_scale;
-    return k;
-}
-
-static float adam_step_size(double lr, double beta1, int step) { return (float)(lr / (1.0 - pow(beta1, (double)step))); }
-
 void ngs_launch_adam_flat(hipStream_t s, long long n, float* param, const float* grad, float* exp_avg,
                           float* exp_avg_sq, double lr_head, double lr_tail, int period, int head, double beta1,
                           double beta2, double eps, int step, float grad_scale)
 {
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, n, param, grad,
-                       exp_avg, exp_avg_sq, adam_step_size(lr_head, beta1, step), adam_step_size(lr_tail, beta1, step),
-                       period, head, adam_const(beta1, beta2, eps, step, grad_scale));
+                       exp_avg, exp_avg_sq, ngs_adam_step_size(lr_head, beta1, step), ngs_adam_step_size(lr_tail, beta1, step),
+                       period, head, ngs_adam_const(beta1, beta2, eps, step, grad_scale));
 }
 
 void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const float* const grad[3],
@@ -413,9 +384,9 @@ void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const 
         g[i].exp_avg = exp_avg[i];
         g[i].exp_avg_sq = exp_avg_sq[i];
         g[i].activated = activated[i];
-        g[i].step = adam_step_size(lr[i], beta1, step);
+        g[i].step = ngs_adam_step_size(lr[i], beta1, step);
     }
     hipLaunchKernelGGL(adam_activated_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g[0], g[1], g[2],
-                       adam_const(beta1, beta2, eps, step, grad_scale), dL_dmean2D, radii, grad_accum, denom,
+                       ngs_adam_const(beta1, beta2, eps, step, grad_scale), dL_dmean2D, radii, grad_accum, denom,
                        max_radii);
 }

@@ -34,6 +34,7 @@ def lib():
         L.ngs_required_binning_bytes.argtypes = [ctypes.c_longlong]
         L.ngs_rasterize_forward.restype = ctypes.c_int
         L.ngs_rasterize_backward.restype = ctypes.c_int
+        L.ngs_rasterize_backward_sh_adam.restype = ctypes.c_int
         L.ngs_mark_visible.restype = ctypes.c_int
         L.ngs_state_layout.restype = ctypes.c_int
         L.ngs_masked_color_gradient.restype = ctypes.c_int
@@ -142,13 +143,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 return_conic=False, out=None, skip_sh=False):
+                                 return_conic=False, out=None, skip_sh=False, sh_adam=None):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     (rasterize_points.cu:195); with ``return_conic`` a ninth element dL_dconic [P,2,2] is appended.
     ``out`` may map any of those names to a preallocated contiguous float32 tensor of the right size (for
     instance a slice of one flat gradient bucket that is all-reduced afterwards); the rest are allocated here.
     With ``skip_sh`` the SH coefficient gradient is not produced (None in its place): a view-parallel caller
-    rebuilds it for all views at once with ``sh_gradient_from_views``."""
+    rebuilds it for all views at once with ``sh_gradient_from_views``.
+    ``sh_adam`` = dict(exp_avg, exp_avg_sq, lr_dc, lr_rest, step[, betas, eps, grad_scale]) fuses the optimiser step
+    of the SH coefficients into the pass: ``sh`` ([P,16,3]) is updated IN PLACE and no SH gradient is returned."""
     _require_gpu(means3D)
     dev = means3D.device
     P = means3D.size(0)
@@ -177,10 +180,30 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dconic = mk("dL_dconic", (P, 2, 2)) if return_conic else None
     dL_dopacity = mk("dL_dopacity", (P, 1))
     dL_dcov3D = mk("dL_dcov3D", (P, 6))
-    dL_dsh = None if skip_sh else mk("dL_dsh", (P, M, 3))
+    dL_dsh = None if (skip_sh or sh_adam is not None) else mk("dL_dsh", (P, M, 3))
+    if sh_adam is not None:
+        if sh.numel() == 0 or M != 16:
+            raise RuntimeError("the fused SH optimiser step needs SH coefficients of shape (P, 16, 3)")
+        for t in (sh_adam["exp_avg"], sh_adam["exp_avg_sq"]):
+            if t.shape != sh.shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                raise RuntimeError("Adam moments must be contiguous float32 tensors shaped like the SH coefficients")
     dL_dscales = mk("dL_dscales", (P, 3))
     dL_drotations = mk("dL_drotations", (P, 4))
-    if P != 0:
+    if P != 0 and sh_adam is not None:
+        betas = sh_adam.get("betas", (0.9, 0.999))
+        with torch.cuda.device(dev):
+            _check(lib().ngs_rasterize_backward_sh_adam(
+                P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(scales),
+                ctypes.c_float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                _ptr(projmatrix), _ptr(campos), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy),
+                _ptr(radii.contiguous()), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dscales), _ptr(dL_drotations),
+                _ptr(sh_adam["exp_avg"]), _ptr(sh_adam["exp_avg_sq"]), ctypes.c_double(sh_adam["lr_dc"]),
+                ctypes.c_double(sh_adam["lr_rest"]), ctypes.c_double(betas[0]), ctypes.c_double(betas[1]),
+                ctypes.c_double(sh_adam.get("eps", 1e-15)), int(sh_adam["step"]),
+                ctypes.c_float(sh_adam.get("grad_scale", 1.0)), int(bool(debug)), _stream(dev)))
+    elif P != 0:
         with torch.cuda.device(dev):
             _check(lib().ngs_rasterize_backward(
                 P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),

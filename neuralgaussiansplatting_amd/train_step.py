@@ -122,15 +122,24 @@ class GaussianTrainer:
             return dL
 
         scene = self.scene_view()
-        color, radii, aux = view_parallel.forward_backward(scene, cam, bg, loss_grad, self.exchange, tanfovx, tanfovy)
+        # On one rank the SH coefficients (four fifths of all parameters) are stepped inside the backward pass: their
+        # gradient is consumed where it is produced instead of travelling through memory to a separate Adam kernel.
+        fused_sh = self.world == 1 and self.M == 16
+        sh_adam = None
+        if fused_sh:
+            m, v = self.state["features"]
+            sh_adam = dict(exp_avg=m, exp_avg_sq=v, lr_dc=o.feature_lr, lr_rest=o.feature_lr / 20.0, step=it)
+        color, radii, aux = view_parallel.forward_backward(scene, cam, bg, loss_grad, self.exchange, tanfovx, tanfovy,
+                                                           sh_adam=sh_adam)
         self.exchange.reduce(scene, cam, aux)
         g = self.exchange.shaped()
         scale = 1.0 / self.world  # the batch loss is the mean over the views of all ranks
         m, v = self.state["xyz"]
         _C.adam_step(self.xyz, g["dL_dmeans3D"], m, v, self.xyz_lr(it), it, grad_scale=scale)
-        m, v = self.state["features"]
-        _C.adam_step(self.features, g["dL_dsh"], m, v, o.feature_lr, it, lr_tail=o.feature_lr / 20.0,
-                     period=3 * self.M, head=3, grad_scale=scale)
+        if not fused_sh:
+            m, v = self.state["features"]
+            _C.adam_step(self.features, g["dL_dsh"], m, v, o.feature_lr, it, lr_tail=o.feature_lr / 20.0,
+                         period=3 * self.M, head=3, grad_scale=scale)
         names = ("opacity_raw", "scaling_raw", "rotation_raw")
         densify = None
         if self.densify_stats:

@@ -169,11 +169,13 @@ def shard_views(num_views, rank, world_size):
     return list(range(rank, num_views, world_size))
 
 
-def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale_modifier=1.0, debug=False):
+def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale_modifier=1.0, debug=False,
+                     sh_adam=None):
     """One pass of the hot path for one view on this rank's GPU: rasterize,
     obtain dL/dpixel from ``dL_dpix_fn(color)``, run the backward pass with the
     parameter gradients landing in ``bucket`` (either exchange form; ``bucket.reduce(scene, cam, aux)`` then
-    sums them over the ranks).  Returns (color, radii, aux)."""
+    sums them over the ranks).  ``sh_adam`` (see ``_C.rasterize_gaussians_backward``) makes the backward pass
+    apply the SH coefficients' optimiser step itself; single-rank steps only.  Returns (color, radii, aux)."""
     e = torch.empty(0)
     H, W = int(cam.image_height), int(cam.image_width)
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(
@@ -184,5 +186,5 @@ def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale
     res = _C.rasterize_gaussians_backward(
         bg, scene.means3D, radii, e, scene.scales, scene.rotations, scale_modifier, e, cam.world_view_transform,
         cam.full_proj_transform, tanfovx, tanfovy, dL_dpix, scene.shs, scene.sh_degree, cam.camera_center, geom, R,
-        binning, img, debug, out=bucket.views, skip_sh=bucket.skip_sh)
+        binning, img, debug, out=bucket.views, skip_sh=bucket.skip_sh, sh_adam=sh_adam)
     return color, radii, dict(num_rendered=R, dL_dmeans2D=res[0], dL_dcolors=res[1], dL_dcov3D=res[4], geom=geom)
