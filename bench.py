@@ -199,11 +199,20 @@ def main():
         train_stages = _C.profile_read(reset=True)
         _C.profile_enable(False)
         note("training iterations done")
+        in_sync = None
         if world > 1:
-            t = torch.tensor([t_train], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            cdev = dev if args.backend == "nccl" else "cpu"
+            t = torch.tensor([t_train], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             t_train = float(t.item())
-        train = (t_train, train_stages)
+            # the replicas must have stayed bit-identical: every rank applied the same all-view gradients
+            sums = torch.stack([p.double().sum() for p in (trainer.xyz, trainer.features, trainer.opacity_raw,
+                                                           trainer.scaling_raw, trainer.rotation_raw)]).to(cdev)
+            hi, lo = sums.clone(), sums.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            in_sync = bool(torch.equal(hi, lo))
+        train = (t_train, train_stages, in_sync)
 
     # ---- third loop: the index-map operator (nearest centre per pixel) on the same scene and view ----
     idxmap = None
@@ -281,7 +290,7 @@ def main():
             cpu = cpu_baseline(scene_cpu, synthetic.make_view(W, H, index=0, count=8), W, H, D, tanx, tany, dL)
         train_out = None
         if train is not None:
-            t_train, train_stages = train
+            t_train, train_stages, in_sync = train
             per_iter = {}
             fused = world == 1 and M == 16
             for name, (tot, cnt) in train_stages.items():
@@ -297,7 +306,7 @@ def main():
                                  "activations and densification statistics, fixed random target image"
                                  % (" with the SH coefficients' Adam step inside" if fused else "",
                                     "gradient exchange + " if world > 1 else ""),
-                         "stages": per_iter}
+                         "replicas_in_sync": in_sync, "stages": per_iter}
         line = {
             "metric": "fwd+bwd Mpixels/s (rasterizer forward+backward, 1080p / 3M Gaussians per GPU)"
                       if args.config == "c4" else "fwd+bwd Mpixels/s (rasterizer forward+backward)",

@@ -123,8 +123,16 @@ size_t ngs_required_image_bytes(int width, int height);
  * ngs_sh_gradient_from_views: campos holds V positions campos_stride floats apart, dL_dcolor_views holds V
  * arrays [P][3] view_stride floats apart (so both may point into one gathered buffer); dL_dsh is [P][M][3] and
  * every element is written.
+ *
+ * ngs_sh_adam_from_views: as ngs_sh_gradient_from_views, but the summed gradient is not written: the Adam step of
+ * the SH coefficients is applied to `shs` ([P][16][3], in place) and its moments directly (arguments as in
+ * ngs_rasterize_backward_sh_adam; grad_scale = 1/V turns the sum into the mean over the views).
  */
 int ngs_masked_color_gradient(int P, const char* geom_buffer, const float* dL_dcolor, float* out, void* stream);
+int ngs_sh_adam_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
+                           long long campos_stride, const float* dL_dcolor_views, long long view_stride, float* shs,
+                           float* sh_exp_avg, float* sh_exp_avg_sq, double lr_dc, double lr_rest, double beta1,
+                           double beta2, double eps, int step, float grad_scale, void* stream);
 int ngs_sh_gradient_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
                                long long campos_stride, const float* dL_dcolor_views, long long view_stride,
                                float* dL_dsh, void* stream);

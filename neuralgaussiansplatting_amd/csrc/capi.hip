@@ -481,7 +481,7 @@ extern "C" int ngs_sh_gradient_from_views(int P, int D, int M, int V, const floa
     const int ps = prof_acquire();
     prof_begin(ps, ST_SH_VIEWS, (hipStream_t)stream);
     ngs_launch_sh_from_views((hipStream_t)stream, P, D, M, V, means3D, campos, campos_stride, dL_dcolor_views,
-                             view_stride, dL_dsh);
+                             view_stride, dL_dsh, nullptr);
     prof_end(ps, ST_SH_VIEWS, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("stage SH gradient from views", hipGetErrorString(e));
@@ -631,6 +631,41 @@ extern "C" int ngs_idxmap_backward(int P, int width, int height, const float* me
                                dL_dout_feature, dL_dfeature_vector);
     prof_end(ps, ST_IDXMAP_BWD, st);
     NGS_STAGE("index map backward");
+    return 0;
+}
+
+extern "C" int ngs_sh_adam_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
+                                      long long campos_stride, const float* dL_dcolor_views, long long view_stride,
+                                      float* shs, float* sh_exp_avg, float* sh_exp_avg_sq, double lr_dc,
+                                      double lr_rest, double beta1, double beta2, double eps, int step,
+                                      float grad_scale, void* stream)
+{
+    const char* fn = "ngs_sh_adam_from_views";
+    g_err[0] = 0;
+    if (P < 0 || V < 1) return fail(fn, "bad sizes");
+    if (M != 16 || D < 0 || D > 3) return fail(fn, "the fused update needs rows of 16 coefficients and a degree of 0..3");
+    if (P == 0) return 0;
+    if (!means3D || !campos || !dL_dcolor_views || !shs || !sh_exp_avg || !sh_exp_avg_sq)
+        return fail(fn, "missing required pointer");
+    if (campos_stride < 3 || view_stride < 3LL * P) return fail(fn, "view strides shorter than one view's data");
+    if (((uintptr_t)shs | (uintptr_t)sh_exp_avg | (uintptr_t)sh_exp_avg_sq) % 16 != 0)
+        return fail(fn, "SH coefficients and optimiser state must be 16-byte aligned");
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0 && step >= 1))
+        return fail(fn, "bad Adam constants or step < 1");
+    ShAdamArgs a;
+    a.param = shs;
+    a.exp_avg = sh_exp_avg;
+    a.exp_avg_sq = sh_exp_avg_sq;
+    a.step_head = ngs_adam_step_size(lr_dc, beta1, step);
+    a.step_tail = ngs_adam_step_size(lr_rest, beta1, step);
+    a.k = ngs_adam_const(beta1, beta2, eps, step, grad_scale);
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_SH_VIEWS, (hipStream_t)stream);
+    ngs_launch_sh_from_views((hipStream_t)stream, P, D, M, V, means3D, campos, campos_stride, dL_dcolor_views,
+                             view_stride, shs /* alignment witness for the LDS path; not written as a gradient */, &a);
+    prof_end(ps, ST_SH_VIEWS, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("stage SH Adam from views", hipGetErrorString(e));
     return 0;
 }
 

@@ -203,7 +203,8 @@ void ngs_launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* 
 // over V views from those masked colour gradients.
 void ngs_launch_masked_color(hipStream_t s, int P, const uint8_t* clamped, const float* dL_dcolor, float* out);
 void ngs_launch_sh_from_views(hipStream_t s, int P, int D, int M, int V, const float* means, const float* campos,
-                              long long campos_stride, const float* colors, long long colors_stride, float* dL_dsh);
+                              long long campos_stride, const float* colors, long long colors_stride, float* dL_dsh,
+                              const ShAdamArgs* sh_adam);
 
 // train_ops.hip: fused L1 + SSIM image loss (value and gradient) and fused Adam + parameter activations.
 size_t ngs_loss_workspace_floats(int W, int H);

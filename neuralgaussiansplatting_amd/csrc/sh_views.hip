@@ -10,6 +10,7 @@
 // they end up with bit-identical sums.  The products are formed by the same
 // expression as the per-view backward (sh_basis_weights), so for V == 1 the
 // result equals the per-view dL_dsh bit for bit.
+#include <string.h>
 #include "ngs_common.h"
 
 #define SH_ROW 48      // floats per Gaussian when M == 16
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void masked_color_kernel(int P, co
 template <bool LDS>
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void sh_from_views_kernel(
     int P, int D, int M, int V, const float* __restrict__ means, const float* __restrict__ campos,
-    long long campos_stride, const float* __restrict__ colors, long long colors_stride, float* __restrict__ dL_dsh)
+    long long campos_stride, const float* __restrict__ colors, long long colors_stride, float* __restrict__ dL_dsh,
+    const ShAdamArgs adam)
 {
     __shared__ float s_sh[LDS ? NGS_GAUSS_BLOCK * SH_ROW_LDS : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,9 +73,24 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void sh_from_views_kernel(
 #pragma unroll
         for (int t = 0; t < SH_ROW * 64 / 4 / 64; t++) {
             const int f = t * 64 + lane, g = f / (SH_ROW / 4), c = f - g * (SH_ROW / 4);
-            if (wave_first + g < P)
-                stream_store4(dL_dsh + (size_t)(wave_first + g) * SH_ROW + 4 * c,
-                              *(const float4*)(wrows + g * SH_ROW_LDS + c * 4));
+            if (wave_first + g >= P) continue;
+            const float4 gr = *(const float4*)(wrows + g * SH_ROW_LDS + c * 4);
+            const size_t o = (size_t)(wave_first + g) * SH_ROW + 4 * c;
+            if (adam.param) {
+                // optimiser step fused in: the summed gradient is consumed here instead of being written out
+                float4 p = stream_load4(adam.param + o), m = stream_load4(adam.exp_avg + o),
+                       v = stream_load4(adam.exp_avg_sq + o);
+                const float s3 = c == 0 ? adam.step_head : adam.step_tail;  // elements 0..2 of a row: the DC term
+                p.x = adam_update(p.x, gr.x * adam.k.grad_scale, m.x, v.x, s3, adam.k);
+                p.y = adam_update(p.y, gr.y * adam.k.grad_scale, m.y, v.y, s3, adam.k);
+                p.z = adam_update(p.z, gr.z * adam.k.grad_scale, m.z, v.z, s3, adam.k);
+                p.w = adam_update(p.w, gr.w * adam.k.grad_scale, m.w, v.w, adam.step_tail, adam.k);
+                stream_store4(adam.param + o, p);
+                stream_store4(adam.exp_avg + o, m);
+                stream_store4(adam.exp_avg_sq + o, v);
+            } else {
+                stream_store4(dL_dsh + o, gr);
+            }
         }
     } else if (idx < P) {
         float3* out = (float3*)(dL_dsh + (size_t)3 * M * i);
@@ -91,13 +108,17 @@ void ngs_launch_masked_color(hipStream_t s, int P, const uint8_t* clamped, const
 }
 
 void ngs_launch_sh_from_views(hipStream_t s, int P, int D, int M, int V, const float* means, const float* campos,
-                              long long campos_stride, const float* colors, long long colors_stride, float* dL_dsh)
+                              long long campos_stride, const float* colors, long long colors_stride, float* dL_dsh,
+                              const ShAdamArgs* sh_adam)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    ShAdamArgs adam;
+    memset(&adam, 0, sizeof adam);
+    if (sh_adam) adam = *sh_adam;  // the caller has checked M == 16 and the alignment
     if (M == 16 && (uintptr_t)dL_dsh % 16 == 0)
         hipLaunchKernelGGL(sh_from_views_kernel<true>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, V, means, campos,
-                           campos_stride, colors, colors_stride, dL_dsh);
+                           campos_stride, colors, colors_stride, dL_dsh, adam);
     else
         hipLaunchKernelGGL(sh_from_views_kernel<false>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, V, means,
-                           campos, campos_stride, colors, colors_stride, dL_dsh);
+                           campos, campos_stride, colors, colors_stride, dL_dsh, adam);
 }

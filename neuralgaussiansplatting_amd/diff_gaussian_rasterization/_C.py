@@ -39,6 +39,7 @@ def lib():
         L.ngs_state_layout.restype = ctypes.c_int
         L.ngs_masked_color_gradient.restype = ctypes.c_int
         L.ngs_sh_gradient_from_views.restype = ctypes.c_int
+        L.ngs_sh_adam_from_views.restype = ctypes.c_int
         L.ngs_loss_workspace_bytes.restype = ctypes.c_size_t
         L.ngs_l1_ssim_loss.restype = ctypes.c_int
         L.ngs_adam_step.restype = ctypes.c_int
@@ -234,11 +235,13 @@ def masked_color_gradient(geomBuffer, dL_dcolors, out=None):
     return out.view(P, 3)
 
 
-def sh_gradient_from_views(means3D, campos, dL_dcolor_views, degree, M, out=None):
+def sh_gradient_from_views(means3D, campos, dL_dcolor_views, degree, M, out=None, sh_adam=None):
     """Sum over views of the SH coefficient gradient, rebuilt from per-view masked colour gradients.
 
     ``campos`` [V,3] and ``dL_dcolor_views`` [V,P,3] may be strided along the view axis (rows of one gathered
-    buffer) but must be contiguous within a view.  -> dL_dsh [P,M,3]."""
+    buffer) but must be contiguous within a view.  -> dL_dsh [P,M,3].
+    With ``sh_adam`` = dict(param, exp_avg, exp_avg_sq, lr_dc, lr_rest, step[, betas, eps, grad_scale]) the sum is
+    not written: the coefficients ``param`` [P,16,3] take their Adam step in place, and None is returned."""
     _require_gpu(means3D)
     dev = means3D.device
     P, V = means3D.size(0), dL_dcolor_views.size(0)
@@ -248,13 +251,27 @@ def sh_gradient_from_views(means3D, campos, dL_dcolor_views, degree, M, out=None
             raise RuntimeError("view data must be float32 on %s" % dev)
         if t.size(0) != V or t[0].numel() != inner or not t[0].is_contiguous():
             raise RuntimeError("view data must hold one contiguous block of %d floats per view" % inner)
+    cs = campos.stride(0) if V > 1 else 3
+    vs = dL_dcolor_views.stride(0) if V > 1 else 3 * P
+    if sh_adam is not None:
+        for t in (sh_adam["param"], sh_adam["exp_avg"], sh_adam["exp_avg_sq"]):
+            if t.shape != (P, 16, 3) or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                raise RuntimeError("the fused SH optimiser step needs contiguous float32 [P,16,3] tensors on %s" % dev)
+        betas = sh_adam.get("betas", (0.9, 0.999))
+        if P != 0:
+            with torch.cuda.device(dev):
+                _check(lib().ngs_sh_adam_from_views(
+                    P, int(degree), 16, V, _ptr(means3D), _ptr(campos), ctypes.c_longlong(cs),
+                    _ptr(dL_dcolor_views), ctypes.c_longlong(vs), _ptr(sh_adam["param"]), _ptr(sh_adam["exp_avg"]),
+                    _ptr(sh_adam["exp_avg_sq"]), ctypes.c_double(sh_adam["lr_dc"]), ctypes.c_double(sh_adam["lr_rest"]),
+                    ctypes.c_double(betas[0]), ctypes.c_double(betas[1]), ctypes.c_double(sh_adam.get("eps", 1e-15)),
+                    int(sh_adam["step"]), ctypes.c_float(sh_adam.get("grad_scale", 1.0)), _stream(dev)))
+        return None
     if out is None:
         out = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
     elif out.numel() != 3 * M * P or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous():
         raise RuntimeError("out must be a contiguous float32 tensor with %d elements on %s" % (3 * M * P, dev))
     if P != 0:
-        cs = campos.stride(0) if V > 1 else 3
-        vs = dL_dcolor_views.stride(0) if V > 1 else 3 * P
         with torch.cuda.device(dev):
             _check(lib().ngs_sh_gradient_from_views(
                 P, int(degree), int(M), V, _ptr(means3D), _ptr(campos), ctypes.c_longlong(cs),

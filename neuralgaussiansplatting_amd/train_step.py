@@ -124,16 +124,19 @@ class GaussianTrainer:
         scene = self.scene_view()
         # On one rank the SH coefficients (four fifths of all parameters) are stepped inside the backward pass: their
         # gradient is consumed where it is produced instead of travelling through memory to a separate Adam kernel.
-        fused_sh = self.world == 1 and self.M == 16
+        scale = 1.0 / self.world  # the batch loss is the mean over the views of all ranks
+        factored = isinstance(self.exchange, view_parallel.FactoredGradientExchange)
+        fused_sh = self.M == 16 and (self.world == 1 or factored)
         sh_adam = None
         if fused_sh:
             m, v = self.state["features"]
-            sh_adam = dict(exp_avg=m, exp_avg_sq=v, lr_dc=o.feature_lr, lr_rest=o.feature_lr / 20.0, step=it)
+            sh_adam = dict(param=self.features, exp_avg=m, exp_avg_sq=v, lr_dc=o.feature_lr,
+                           lr_rest=o.feature_lr / 20.0, step=it, grad_scale=scale)
+        # one rank: inside the backward pass; several ranks: inside the kernel that rebuilds the all-view SH gradient
         color, radii, aux = view_parallel.forward_backward(scene, cam, bg, loss_grad, self.exchange, tanfovx, tanfovy,
-                                                           sh_adam=sh_adam)
-        self.exchange.reduce(scene, cam, aux)
+                                                           sh_adam=sh_adam if self.world == 1 else None)
+        self.exchange.reduce(scene, cam, aux, sh_adam=sh_adam if (self.world > 1 and fused_sh) else None)
         g = self.exchange.shaped()
-        scale = 1.0 / self.world  # the batch loss is the mean over the views of all ranks
         m, v = self.state["xyz"]
         _C.adam_step(self.xyz, g["dL_dmeans3D"], m, v, self.xyz_lr(it), it, grad_scale=scale)
         if not fused_sh:

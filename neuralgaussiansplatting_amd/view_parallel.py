@@ -93,8 +93,10 @@ class GradientBucket:
         return None
 
 
-    def reduce(self, scene=None, cam=None, aux=None, group=None):
+    def reduce(self, scene=None, cam=None, aux=None, group=None, sh_adam=None):
         """Uniform entry point of both exchange forms (the dense one needs none of the arguments)."""
+        if sh_adam is not None:
+            raise RuntimeError("the dense exchange has no fused SH optimiser step")
         return self.all_reduce(group=group)
 
 
@@ -135,9 +137,11 @@ class FactoredGradientExchange:
         """Payload each rank contributes to the two collectives (float32 bytes)."""
         return 4 * (self.row + self.reduced.numel())
 
-    def reduce(self, scene, cam, aux, group=None):
+    def reduce(self, scene, cam, aux, group=None, sh_adam=None):
         """``aux`` is what ``forward_backward`` returned for this rank's view (it carries the geometry buffer with
-        the clamp flags and the raw colour gradient)."""
+        the clamp flags and the raw colour gradient).  With ``sh_adam`` (see ``_C.sh_gradient_from_views``) the
+        rebuilt SH gradient is consumed by the coefficients' Adam step on the spot and ``shaped()['dL_dsh']`` is
+        not updated."""
         group = group if group is not None else self.group
         P = self.P
         _C.masked_color_gradient(aux["geom"], aux["dL_dcolors"], out=self.local[:3 * P])
@@ -158,7 +162,7 @@ class FactoredGradientExchange:
         else:
             gathered = self.local.view(1, self.row)
         _C.sh_gradient_from_views(scene.means3D, gathered[:, 3 * P:3 * P + 3], gathered[:, :3 * P], scene.sh_degree,
-                                  self.M, out=self.dL_dsh)
+                                  self.M, out=self.dL_dsh, sh_adam=sh_adam)
         if pending is not None:
             pending.wait()
         return None

@@ -125,6 +125,31 @@ def test_adam_step_activated_matches_autograd_chain(C):
     assert torch.equal(maxr, torch.maximum(torch.ones_like(radii), radii))
 
 
+def test_fused_sh_adam_from_views_equals_gradient_then_adam(C):
+    """Multi-view form of the fused step: rebuilding the all-view SH gradient and stepping Adam in one kernel must
+    give exactly what the two separate kernels give."""
+    gen = torch.Generator().manual_seed(12)
+    P, V, D = 1300, 3, 3
+    means = torch.randn(P, 3, generator=gen).to(DEV)
+    campos = (torch.randn(V, 3, generator=gen) * 4).to(DEV)
+    colors = torch.randn(V, P * 3, generator=gen).to(DEV)
+    colors[1, : 3 * 200] = 0.0
+    sh0 = torch.randn(P, 16, 3, generator=gen).to(DEV)
+    m0 = (torch.randn(P, 16, 3, generator=gen) * 0.1).to(DEV)
+    v0 = (torch.rand(P, 16, 3, generator=gen) * 0.01).to(DEV)
+    kw = dict(lr_dc=0.0025, lr_rest=0.0025 / 20.0, step=7, grad_scale=1.0 / V)
+    grad = C.sh_gradient_from_views(means, campos, colors, D, 16)
+    p1, m1, v1 = sh0.clone(), m0.clone(), v0.clone()
+    C.adam_step(p1, grad, m1, v1, kw["lr_dc"], kw["step"], lr_tail=kw["lr_rest"], period=48, head=3,
+                grad_scale=kw["grad_scale"])
+    p2, m2, v2 = sh0.clone(), m0.clone(), v0.clone()
+    assert C.sh_gradient_from_views(means, campos, colors, D, 16,
+                                    sh_adam=dict(param=p2, exp_avg=m2, exp_avg_sq=v2, **kw)) is None
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+    assert not torch.equal(p2, sh0)
+
+
 def test_training_iterations_match_pytorch_assembly(C):
     """Three iterations of GaussianTrainer against the same iterations assembled the reference's way: separate
     f_dc / f_rest parameters concatenated per iteration, activations and loss as PyTorch operators under autograd

@@ -70,7 +70,7 @@ def _factored_worker(rank, world, port, P, M, D, ret):
             out.copy_((dL_dcolors * geom).reshape(-1))
             return out
 
-        def sh_from_views(means3D, campos, colors, degree, M_, out=None):
+        def sh_from_views(means3D, campos, colors, degree, M_, out=None, sh_adam=None):
             assert campos.shape == (world, 3) and colors.shape == (world, 3 * P)
             out.copy_(_sh_sum(means3D, campos, colors, degree, M_))
             return out
