@@ -101,7 +101,7 @@ def main():
                     help="full training iterations (render + L1/D-SSIM loss + backward + exchange + Adam) timed in a "
                          "second loop for the train iters/s figure; default: --steps, 0 to skip")
     ap.add_argument("--no-idxmap", action="store_true",
-                    help="skip the third loop (index-map operator of the reference's second rasterizer, forward+backward)")
+                    help="skip the side measurements: the index-map operator of the reference's second rasterizer (forward+backward) and the nearest-neighbour scene initialisation")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
@@ -250,6 +250,20 @@ def main():
                   "stages": {k: {"ms": round(tot / cnt, 4), "algorithmic_GB": round(nb[k] / 1e9, 4),
                                  "GB_per_s": round(nb[k] / (tot / cnt * 1e-3) / 1e9, 1)}
                              for k, (tot, cnt) in st.items() if cnt and k in nb}}
+    # ---- scene initialisation: mean squared distance to the three nearest neighbours of the scene's centres ----
+    scene_init = None
+    if not args.no_idxmap and rank == 0:
+        from neuralgaussiansplatting_amd.simple_knn._C import distCUDA2
+        distCUDA2(scene.means3D)
+        torch.cuda.synchronize(dev)
+        reps = max(1, min(args.steps, 5))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            distCUDA2(scene.means3D)
+        torch.cuda.synchronize(dev)
+        t_knn = (time.perf_counter() - t0) / reps
+        scene_init = {"knn_ms": round(t_knn * 1e3, 3), "Mpoints_per_s": round(P / t_knn / 1e6, 1),
+                      "what": "distCUDA2 on the scene's %d centres (once per scene, not per iteration)" % P}
     if world > 1:
         dist.barrier()
 
@@ -324,6 +338,7 @@ def main():
                        "last_contributor_per_pixel_mean": round(float(stt["n_contrib"].mean()), 1),
                        "parallelism": "view-sharded dp%d" % world},
             "roofline": roofline, "cpu_baseline": cpu, "stages": stage_out, "train": train_out, "idxmap": idxmap,
+            "scene_init": scene_init,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

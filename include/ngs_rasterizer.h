@@ -207,6 +207,18 @@ int ngs_idxmap_backward(int P, int width, int height, const float* means3D, cons
                         const float* projmatrix, int debug, void* stream);
 
 /*
+ * Scene initialisation: mean_dist2[i] = mean of the squared distances from point i to its three nearest other
+ * points = SimpleKNN::knn (submodules/simple-knn/simple_knn.h:16-19, simple_knn.cu:185-221), the routine behind
+ * simple_knn._C.distCUDA2 (spatial.cu:15-26, ext.cpp:15-17), whose result scene/gaussian_model.py:160-161 turns into
+ * the initial scales.  points [P][3], mean_dist2 [P] (every element written).  The search is exact, as the
+ * reference's is; with fewer than three other points the FLT_MAX sentinels of the missing neighbours enter the
+ * mean as they do in the reference (+inf for P < 3, FLT_MAX / 3 for P == 3).  The reference allocates its temporaries inside the call; here they live in a caller-owned
+ * workspace of ngs_knn_workspace_bytes(P) bytes (any alignment; about 52 bytes per point).
+ */
+size_t ngs_knn_workspace_bytes(int P);
+int ngs_knn_mean_dist2(int P, const float* points, float* mean_dist2, char* workspace, int debug, void* stream);
+
+/*
  * Introspection for parity tests: byte offsets (relative to the 256-byte
  * aligned base of each buffer) of the intermediate arrays, in this order:
  *  geometry[10]: splat_record(16 floats per Gaussian: x, y, conic a, b, c, opacity, r, g, b, 7 unused),

@@ -41,13 +41,13 @@ static int fail(const char* what, const char* detail)
 enum {
     ST_PREPROCESS, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SEGSORT, ST_RENDER_FWD,
     ST_BWD_ZERO, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_SH_VIEWS, ST_LOSS, ST_ADAM_FLAT, ST_ADAM_ACTIVATED,
-    ST_IDXMAP_FWD, ST_IDXMAP_BWD, ST_COUNT
+    ST_IDXMAP_FWD, ST_IDXMAP_BWD, ST_KNN, ST_COUNT
 };
 static const char* const g_stage_names[ST_COUNT] = {
     "preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort_tile_bits", "tile_ranges", "segment_sort_depth",
     "render_fwd",
     "zero_accumulator", "render_bwd", "preprocess_bwd", "sh_gradient_from_views", "l1_ssim_loss", "adam_identity_groups",
-    "adam_activated_groups", "idxmap_forward", "idxmap_backward"};
+    "adam_activated_groups", "idxmap_forward", "idxmap_backward", "knn_mean_dist2"};
 #define PROF_RING 32
 struct ProfSlot {
     hipEvent_t ev[ST_COUNT][2];
@@ -631,6 +631,24 @@ extern "C" int ngs_idxmap_backward(int P, int width, int height, const float* me
                                dL_dout_feature, dL_dfeature_vector);
     prof_end(ps, ST_IDXMAP_BWD, st);
     NGS_STAGE("index map backward");
+    return 0;
+}
+
+extern "C" size_t ngs_knn_workspace_bytes(int P) { return P > 0 ? ngs_knn_workspace_size(P) : 0; }
+
+extern "C" int ngs_knn_mean_dist2(int P, const float* points, float* mean_dist2, char* workspace, int debug,
+                                  void* stream)
+{
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0) return fail("ngs_knn_mean_dist2", "bad sizes");
+    if (P == 0) return 0;
+    if (!points || !mean_dist2 || !workspace) return fail("ngs_knn_mean_dist2", "missing required pointer");
+    const int ps = prof_acquire();
+    prof_begin(ps, ST_KNN, st);
+    ngs_launch_knn(st, P, points, workspace, mean_dist2);
+    prof_end(ps, ST_KNN, st);
+    NGS_STAGE("nearest neighbours");
     return 0;
 }
 

@@ -220,6 +220,10 @@ void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const 
                                float* denom, int* max_radii);
 
 // idxmap.hip: nearest-centre index map of the reference's second rasterizer and its backward.
+// knn.hip: mean squared distance to the three nearest neighbours (scene initialisation)
+size_t ngs_knn_workspace_size(int P);
+void ngs_launch_knn(hipStream_t s, int P, const float* points, char* workspace, float* mean_dist2);
+// idxmap.hip
 size_t ngs_idxmap_workspace_size(int W, int H);
 void ngs_launch_idxmap_forward(hipStream_t s, int P, int W, int H, const float* means, const float* view,
                                const float* proj, const float* campos, const float* feature_vector, char* workspace,

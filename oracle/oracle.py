@@ -20,7 +20,7 @@ _lib = None
 
 
 def build(force=False):
-    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ngs_oracle.c", "ngs_oracle_idxmap.c"))
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ngs_oracle.c", "ngs_oracle_idxmap.c", "ngs_oracle_knn.c"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libngs_oracle.so"])
     return _LIB_PATH
@@ -207,3 +207,15 @@ def idxmap_backward(P, idx, dL_dfeature):
     out = np.zeros((P, IDXMAP_FEATURES), np.float32)
     lib().ngs_oracle_idxmap_backward(int(P), int(W), int(H), _p(idx), _p(dL_dfeature), _p(out))
     return out
+
+
+def knn_mean_dist2(points, return_order=False):
+    """The reference's simple-knn routine (ngs_oracle_knn.c): [P,3] -> mean squared distance to the three nearest
+    other points [P] (and, on request, the Morton order of the points)."""
+    points = _f32(points)
+    P = points.shape[0]
+    out = np.zeros(P, np.float32)
+    order = np.zeros(P, np.uint32)
+    if lib().ngs_oracle_knn(int(P), _p(points), _p(out), _p(order)) != 0:
+        raise MemoryError("knn oracle: allocation failed")
+    return (out, order) if return_order else out

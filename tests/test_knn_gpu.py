@@ -1,0 +1,76 @@
+"""GPU parity of the nearest-neighbour routine (through the C ABI) against the checker's restatement of the
+reference's simple-knn.  Bar: bit-exact -- both evaluate dx*dx + dy*dy + dz*dz without contraction, the search is
+exact on both sides, and the mean is formed in the same order."""
+import numpy as np
+import pytest
+import torch
+
+from test_knn_cpu import knn_points
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def dist2():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from neuralgaussiansplatting_amd.simple_knn._C import _lib, distCUDA2
+    _lib()
+    return distCUDA2
+
+
+@pytest.mark.parametrize("kind,P", [("uniform", 20000), ("clusters", 100000), ("plane", 30000), ("duplicates", 10000),
+                                    ("positive_octant", 5000)])
+def test_knn_matches_oracle(kind, P, dist2, oracle):
+    pts = knn_points(kind, P, seed=11)
+    got = dist2(torch.tensor(pts, device=DEV)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.knn_mean_dist2(pts))
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 63, 64, 65, 127, 4095, 4096, 4097, 4161])
+def test_knn_ragged_sizes(P, dist2, oracle):
+    pts = knn_points("uniform", P, seed=P)
+    got = dist2(torch.tensor(pts, device=DEV)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.knn_mean_dist2(pts))
+
+
+def test_knn_empty_and_bad_shapes(dist2):
+    assert dist2(torch.zeros((0, 3), device=DEV)).shape == (0,)
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        dist2(torch.zeros((5, 4), device=DEV))
+    with pytest.raises(RuntimeError, match="float32"):
+        dist2(torch.zeros((5, 3), device=DEV, dtype=torch.float64))
+
+
+def test_knn_all_points_identical(dist2, oracle):
+    pts = np.full((1000, 3), 0.25, np.float32)
+    got = dist2(torch.tensor(pts, device=DEV)).cpu().numpy()
+    assert not got.any()
+    np.testing.assert_array_equal(got, oracle.knn_mean_dist2(pts))
+
+
+def test_knn_full_size_scene(dist2, oracle):
+    """3 M points, the benchmark scene's positions: against the checker on every point, and against a k-d tree on a
+    sample (independent of both implementations)."""
+    from scipy.spatial import cKDTree
+    pts = knn_points("uniform", 3_000_000, seed=1234)
+    got = dist2(torch.tensor(pts, device=DEV)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.knn_mean_dist2(pts))
+    sample = np.random.RandomState(0).choice(pts.shape[0], 20000, replace=False)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts[sample].astype(np.float64), k=4)
+    np.testing.assert_allclose(got[sample], (d[:, 1:] ** 2).mean(axis=1), rtol=2e-6)
+
+
+def test_create_from_pcd(dist2):
+    from neuralgaussiansplatting_amd.gaussian_model import GaussianModel
+    from neuralgaussiansplatting_amd.ply_io import BasicPointCloud
+    from neuralgaussiansplatting_amd.sh_utils import SH2RGB
+    rng = np.random.RandomState(2)
+    pcd = BasicPointCloud(points=rng.uniform(-1.3, 1.3, (5000, 3)), colors=rng.rand(5000, 3), normals=None)
+    m = GaussianModel(3).create_from_pcd(pcd, 1.0, device=DEV)
+    want = torch.log(torch.sqrt(torch.clamp_min(dist2(m.get_xyz.detach()), 1e-7)))
+    assert torch.equal(m._scaling[:, 0], want) and torch.equal(m._scaling[:, 1], m._scaling[:, 2])
+    assert m.get_features.shape == (5000, 16, 3) and not m._features_rest.any()
+    np.testing.assert_allclose(SH2RGB(m._features_dc[:, 0, :]).detach().cpu().numpy(), pcd.colors, atol=1e-6)
+    assert torch.allclose(m.get_opacity, torch.full((5000, 1), 0.1, device=DEV))
+    assert torch.equal(m.get_rotation, torch.tensor([[1.0, 0, 0, 0]], device=DEV).expand(5000, 4))
