@@ -99,6 +99,26 @@ int ngs_rasterize_backward_sh_adam(int P, int D, int M, int R, const float* back
                                    double beta1, double beta2, double eps, int step, float grad_scale, int debug,
                                    void* stream);
 
+/*
+ * ngs_rasterize_backward for callers that exchange gradients between GPUs.  No counterpart in the reference
+ * (single GPU).  Arguments as ngs_rasterize_backward, plus: masked_color [P][3] receives the colour gradient with
+ * the channels clamped in the forward pass zeroed (what ngs_masked_color_gradient computes from dL_dcolor) as soon
+ * as the compositing stage has produced it, i.e. BEFORE the per-Gaussian stage is queued; color_ready (may be NULL)
+ * is then called on the host, once, with color_ready_ctx.  An event the callback records on `stream` therefore
+ * completes when masked_color is final, and a collective that waits for that event (on another stream) runs
+ * concurrently with the per-Gaussian stage.  With P == 0 nothing is written and the callback is not called.
+ */
+int ngs_rasterize_backward_early_color(int P, int D, int M, int R, const float* background, int width, int height,
+                                       const float* means3D, const float* shs, const float* colors_precomp,
+                                       const float* scales, float scale_modifier, const float* rotations,
+                                       const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                       const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                                       char* geom_buffer, char* binning_buffer, char* image_buffer,
+                                       const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                       float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                                       float* dL_dscale, float* dL_drot, int debug, void* stream, float* masked_color,
+                                       void (*color_ready)(void*), void* color_ready_ctx);
+
 /* Rasterizer::markVisible (rasterizer.h:24-29, rasterizer_impl.cu:141-153):
  * present[i] = 1 if Gaussian i passes the near-plane test, else 0 (bytes). */
 int ngs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -343,6 +343,13 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     return 0;
 }
 
+// Optional hand-over between the two backward stages (ngs_rasterize_backward_early_color).
+struct EarlyColor {
+    float* out;
+    void (*ready)(void*);
+    void* ctx;
+};
+
 static int backward_impl(const char* fn, int P, int D, int M, int R, const float* background, int width, int height,
                          const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                          float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -350,7 +357,8 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
                          float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
                          const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                          float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                         float* dL_drot, int debug, void* stream, const ShAdamArgs* sh_adam)
+                         float* dL_drot, int debug, void* stream, const ShAdamArgs* sh_adam,
+                         const EarlyColor* early = nullptr)
 {
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
@@ -384,6 +392,11 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
                           acc);
     prof_end(ps, ST_RENDER_BWD, st);
     NGS_STAGE("render backward");
+    if (early && early->out) {
+        ngs_launch_masked_color_from_acc(st, P, (const uint8_t*)(gb + gl.clamped), acc, early->out);
+        NGS_STAGE("early colour gradient");
+        if (early->ready) early->ready(early->ctx);
+    }
     prof_begin(ps, ST_PREPROCESS_BWD, st);
     // scales == NULL (precomputed covariance) skips the scale/rotation gradients, shs == NULL the SH ones,
     // as in the reference (backward.cu:390-395).
@@ -411,6 +424,27 @@ extern "C" int ngs_rasterize_backward(int P, int D, int M, int R, const float* b
                          tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic,
                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream,
                          nullptr);
+}
+
+extern "C" int ngs_rasterize_backward_early_color(
+    int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
+    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+    float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+    float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream, float* masked_color,
+    void (*color_ready)(void*), void* color_ready_ctx)
+{
+    if (!masked_color) {
+        g_err[0] = 0;
+        return fail("ngs_rasterize_backward_early_color", "missing masked_color");
+    }
+    const EarlyColor early = {masked_color, color_ready, color_ready_ctx};
+    return backward_impl("ngs_rasterize_backward_early_color", P, D, M, R, background, width, height, means3D, shs,
+                         colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                         campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix,
+                         dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                         dL_drot, debug, stream, nullptr, &early);
 }
 
 extern "C" int ngs_rasterize_backward_sh_adam(int P, int D, int M, int R, const float* background, int width,

@@ -202,6 +202,7 @@ void ngs_launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* 
 // sh_views.hip: per-Gaussian colour gradient with the clamp mask applied, and the SH coefficient gradient summed
 // over V views from those masked colour gradients.
 void ngs_launch_masked_color(hipStream_t s, int P, const uint8_t* clamped, const float* dL_dcolor, float* out);
+void ngs_launch_masked_color_from_acc(hipStream_t s, int P, const uint8_t* clamped, const float* acc, float* out);
 void ngs_launch_sh_from_views(hipStream_t s, int P, int D, int M, int V, const float* means, const float* campos,
                               long long campos_stride, const float* colors, long long colors_stride, float* dL_dsh,
                               const ShAdamArgs* sh_adam);

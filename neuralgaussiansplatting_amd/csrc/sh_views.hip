@@ -30,6 +30,22 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void masked_color_kernel(int P, co
     out[3 * i + 2] = dL_dcolor[3 * i + 2] * ((bits & 4u) ? 0.0f : 1.0f);
 }
 
+// The same, read straight from the compositing backward's accumulator rows (floats 6..8 of a row are the colour
+// gradient), so that it is available before the per-Gaussian backward has run.
+__global__ __launch_bounds__(NGS_GAUSS_BLOCK) void masked_color_from_acc_kernel(int P, const uint8_t* __restrict__ clamped,
+                                                                               const float* __restrict__ acc,
+                                                                               float* __restrict__ out)
+{
+    const int idx = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
+    if (idx >= P) return;
+    const size_t i = (size_t)idx;
+    const uint32_t bits = clamped[i];
+    const float* row = acc + i * NGS_ACC_STRIDE;
+    out[3 * i] = row[6] * ((bits & 1u) ? 0.0f : 1.0f);
+    out[3 * i + 1] = row[7] * ((bits & 2u) ? 0.0f : 1.0f);
+    out[3 * i + 2] = row[8] * ((bits & 4u) ? 0.0f : 1.0f);
+}
+
 // One lane per Gaussian.  LDS: M == 16, the 64 rows of a wave (12 KiB contiguous) leave through LDS as coalesced
 // 16-byte stores instead of 64 scattered 192-byte rows.
 template <bool LDS>
@@ -105,6 +121,12 @@ void ngs_launch_masked_color(hipStream_t s, int P, const uint8_t* clamped, const
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
     hipLaunchKernelGGL(masked_color_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, clamped, dL_dcolor, out);
+}
+
+void ngs_launch_masked_color_from_acc(hipStream_t s, int P, const uint8_t* clamped, const float* acc, float* out)
+{
+    const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    hipLaunchKernelGGL(masked_color_from_acc_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, clamped, acc, out);
 }
 
 void ngs_launch_sh_from_views(hipStream_t s, int P, int D, int M, int V, const float* means, const float* campos,

@@ -141,10 +141,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return rendered.value, out_color, radii, geom.t, binning.t, img.t
 
 
+_READY_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 return_conic=False, out=None, skip_sh=False, sh_adam=None):
+                                 return_conic=False, out=None, skip_sh=False, sh_adam=None, early_color=None):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     (rasterize_points.cu:195); with ``return_conic`` a ninth element dL_dconic [P,2,2] is appended.
     ``out`` may map any of those names to a preallocated contiguous float32 tensor of the right size (for
@@ -152,7 +155,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     With ``skip_sh`` the SH coefficient gradient is not produced (None in its place): a view-parallel caller
     rebuilds it for all views at once with ``sh_gradient_from_views``.
     ``sh_adam`` = dict(exp_avg, exp_avg_sq, lr_dc, lr_rest, step[, betas, eps, grad_scale]) fuses the optimiser step
-    of the SH coefficients into the pass: ``sh`` ([P,16,3]) is updated IN PLACE and no SH gradient is returned."""
+    of the SH coefficients into the pass: ``sh`` ([P,16,3]) is updated IN PLACE and no SH gradient is returned.
+    ``early_color`` = (tensor of 3P floats, callable or None): the clamp-masked colour gradient (what
+    ``masked_color_gradient`` returns) is written there as soon as the compositing stage has produced it, and the
+    callable is invoked before the per-Gaussian stage is queued -- an event it records on the current stream lets
+    a collective on that data overlap with the rest of the backward pass."""
     _require_gpu(means3D)
     dev = means3D.device
     P = means3D.size(0)
@@ -190,6 +197,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 raise RuntimeError("Adam moments must be contiguous float32 tensors shaped like the SH coefficients")
     dL_dscales = mk("dL_dscales", (P, 3))
     dL_drotations = mk("dL_drotations", (P, 4))
+    if early_color is not None and sh_adam is not None:
+        raise RuntimeError("early_color serves multi-view exchanges, the fused SH step single-view ones: not both")
     if P != 0 and sh_adam is not None:
         betas = sh_adam.get("betas", (0.9, 0.999))
         with torch.cuda.device(dev):
@@ -204,6 +213,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 ctypes.c_double(sh_adam["lr_rest"]), ctypes.c_double(betas[0]), ctypes.c_double(betas[1]),
                 ctypes.c_double(sh_adam.get("eps", 1e-15)), int(sh_adam["step"]),
                 ctypes.c_float(sh_adam.get("grad_scale", 1.0)), int(bool(debug)), _stream(dev)))
+    elif P != 0 and early_color is not None:
+        masked, ready = early_color
+        if masked.numel() != 3 * P or masked.dtype != torch.float32 or masked.device != dev or not masked.is_contiguous():
+            raise RuntimeError("early_color[0] must be a contiguous float32 tensor with %d elements on %s" % (3 * P, dev))
+        cb = _READY_FN((lambda ctx: ready()) if ready is not None else 0)
+        with torch.cuda.device(dev):
+            _check(lib().ngs_rasterize_backward_early_color(
+                P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                _ptr(scales), ctypes.c_float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                _ptr(projmatrix), _ptr(campos), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy),
+                _ptr(radii.contiguous()), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
+                int(bool(debug)), _stream(dev), _ptr(masked), cb, None))
     elif P != 0:
         with torch.cuda.device(dev):
             _check(lib().ngs_rasterize_backward(

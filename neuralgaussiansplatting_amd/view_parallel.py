@@ -125,6 +125,26 @@ class FactoredGradientExchange:
         self.local = torch.zeros(self.row, dtype=torch.float32, device=device)
         self.gathered = torch.zeros((self.world, self.row), dtype=torch.float32, device=device)
         self.dL_dsh = torch.empty((P, M, 3), dtype=torch.float32, device=device)
+        # The masked colour gradient is final once the compositing backward has run; the backward pass hands it
+        # over at that point (``early_color``) and the all-gather starts while the per-Gaussian stage still runs.
+        self._on_gpu = torch.device(device).type == "cuda"
+        self._color_event = torch.cuda.Event() if self._on_gpu else None
+        self._side = torch.cuda.Stream(device=device) if self._on_gpu else None
+        self._early = False
+
+    def begin_view(self, cam):
+        """Called before the backward pass of this rank's view: stores the camera position in the row that will
+        be gathered and returns the ``early_color`` argument of ``_C.rasterize_gaussians_backward``."""
+        P = self.P
+        self.local[3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
+        if not self._on_gpu:
+            return None
+        self._early = False
+        return (self.local[:3 * P], self._color_ready)
+
+    def _color_ready(self):
+        self._color_event.record(torch.cuda.current_stream(self.local.device))
+        self._early = True
 
     def shaped(self):
         P = self.P
@@ -144,14 +164,23 @@ class FactoredGradientExchange:
         not updated."""
         group = group if group is not None else self.group
         P = self.P
-        _C.masked_color_gradient(aux["geom"], aux["dL_dcolors"], out=self.local[:3 * P])
-        self.local[3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
+        early, self._early = self._early, False
+        if not early:  # the backward pass was not given begin_view()'s hand-over: derive the row now
+            _C.masked_color_gradient(aux["geom"], aux["dL_dcolors"], out=self.local[:3 * P])
+            self.local[3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
         pending = None
         grouped = dist.is_available() and dist.is_initialized()
         if grouped and dist.get_backend(group) == "nccl":  # also with a single rank: same calls, trivial traffic
             # both collectives are queued at once; the SH rebuild below needs only the gather, so it runs while the
             # all-reduce of the other gradients is still on the wire
-            gather = dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=group, async_op=True)
+            if early:
+                # the gather waits for the hand-over event only, not for the per-Gaussian stage queued behind it
+                self._side.wait_event(self._color_event)
+                with torch.cuda.stream(self._side):
+                    gather = dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=group,
+                                                         async_op=True)
+            else:
+                gather = dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=group, async_op=True)
             pending = dist.all_reduce(self.reduced, op=dist.ReduceOp.SUM, group=group, async_op=True)
             gather.wait()
             gathered = self.gathered
@@ -187,8 +216,9 @@ def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale
         cam.world_view_transform, cam.full_proj_transform, tanfovx, tanfovy, H, W, scene.shs, scene.sh_degree,
         cam.camera_center, False, debug)
     dL_dpix = dL_dpix_fn(color)
+    early = bucket.begin_view(cam) if sh_adam is None and hasattr(bucket, "begin_view") else None
     res = _C.rasterize_gaussians_backward(
         bg, scene.means3D, radii, e, scene.scales, scene.rotations, scale_modifier, e, cam.world_view_transform,
         cam.full_proj_transform, tanfovx, tanfovy, dL_dpix, scene.shs, scene.sh_degree, cam.camera_center, geom, R,
-        binning, img, debug, out=bucket.views, skip_sh=bucket.skip_sh, sh_adam=sh_adam)
+        binning, img, debug, out=bucket.views, skip_sh=bucket.skip_sh, sh_adam=sh_adam, early_color=early)
     return color, radii, dict(num_rendered=R, dL_dmeans2D=res[0], dL_dcolors=res[1], dL_dcov3D=res[4], geom=geom)

@@ -398,7 +398,13 @@ def test_view_factored_sh_gradient_equals_sum_of_per_view_gradients(D, M, P, dgr
         fact = view_parallel.FactoredGradientExchange(P, M, dev, world_size=1)
         _, _, aux2 = view_parallel.forward_backward(scene, cam, bg, lambda color: dL, fact, c["tanfovx"],
                                                     c["tanfovy"])
+        # the backward pass handed the masked colour gradient over between its two stages: same bits as masking
+        # that run's dL_dcolors afterwards, and the camera position sits behind it
+        assert fact._early
+        assert torch.equal(fact.local[:3 * P], dgr._C.masked_color_gradient(aux2["geom"], aux2["dL_dcolors"]).reshape(-1))
+        assert torch.equal(fact.local[3 * P:3 * P + 3], cam.camera_center.reshape(3))
         fact.reduce(scene, cam, aux2)
+        assert not fact._early
         torch.cuda.synchronize()
         f = fact.shaped()
         for name in view_parallel.BUCKET_FIELDS:
