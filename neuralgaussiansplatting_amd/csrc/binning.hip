@@ -22,17 +22,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
     const int per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
     const int lo = threadIdx.x * per;
     const int hi = min(n, lo + per);
+    __shared__ unsigned long long wave_wide[SCAN_THREADS / 64];
     uint32_t s = 0;
-    for (int i = lo; i < hi; i++) s += in[i];
+    unsigned long long wide = 0;  // the same sum without wrap-around, to notice a count that does not fit
+    for (int i = lo; i < hi; i++) {
+        s += in[i];
+        wide += in[i];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t incl = wave_incl_scan_u32(s, lane);
-    if (lane == 63) wave_tot[wave] = incl;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wide += __shfl_xor(wide, o);
+    if (lane == 63) {
+        wave_tot[wave] = incl;
+        wave_wide[wave] = wide;
+    }
     __syncthreads();
     uint32_t base = 0, total = 0;
+    unsigned long long total_wide = 0;
     for (int w = 0; w < SCAN_THREADS / 64; w++) {
         const uint32_t t = wave_tot[w];
         if (w < wave) base += t;
         total += t;
+        total_wide += wave_wide[w];
     }
     uint32_t run = base + incl - s;
     for (int i = lo; i < hi; i++) {
@@ -41,6 +53,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
         run += v;
     }
     if (threadIdx.x == 0) {
+        if (total_wide > 0x7fffffffull) {  // the count is handed on as a signed 32-bit number
+            misc[1] |= 2u;
+            total = 0xffffffffu;
+        }
         misc[0] = total;
         // The host is spinning on this word of pinned host memory (it holds ~0 until now): the instance count and
         // the error flag reach it without a copy engine or an interrupt in between.

@@ -241,7 +241,7 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
     if (num_rendered) *num_rendered = 0;
-    if (P < 0 || width <= 0 || height <= 0) return fail("ngs_rasterize_forward", "bad sizes");
+    if (P < 0 || P > NGS_MAX_GAUSSIANS || width <= 0 || height <= 0) return fail("ngs_rasterize_forward", "bad sizes");
     if (P == 0) return 0;
     if (!geometry_alloc || !binning_alloc || !image_alloc) return fail("ngs_rasterize_forward", "missing allocator");
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !background || !out_color)
@@ -298,7 +298,7 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
         NGS_HIP(hipStreamSynchronize(st));
     }
     if (host_misc[1] & 1u) return fail("ngs_rasterize_forward", "Point is filtered although prefiltered is set. This shouldn't happen!");
-    if (host_misc[0] > 0x7fffffffu) return fail("ngs_rasterize_forward", "more than 2^31-1 tile instances");
+    if ((host_misc[1] & 2u) || host_misc[0] > 0x7fffffffu) return fail("ngs_rasterize_forward", "more than 2^31-1 tile instances");
     const int64_t R = (int64_t)host_misc[0];
     if (num_rendered) *num_rendered = (int)R;
 
@@ -363,7 +363,7 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
     (void)colors_precomp;
-    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(fn, "bad sizes");
+    if (P < 0 || P > NGS_MAX_GAUSSIANS || R < 0 || width <= 0 || height <= 0) return fail(fn, "bad sizes");
     if (P == 0) return 0;
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(fn, "missing state buffer");
     if (!means3D || !viewmatrix || !projmatrix || !background || !dL_dpix || !dL_dmean2D || !dL_dopacity ||
@@ -504,7 +504,7 @@ extern "C" int ngs_sh_gradient_from_views(int P, int D, int M, int V, const floa
                                           long long view_stride, float* dL_dsh, void* stream)
 {
     g_err[0] = 0;
-    if (P < 0 || V < 1) return fail("ngs_sh_gradient_from_views", "bad sizes");
+    if (P < 0 || P > NGS_MAX_GAUSSIANS || V < 1) return fail("ngs_sh_gradient_from_views", "bad sizes");
     if (D < 0 || D > 3 || (D + 1) * (D + 1) > M)
         return fail("ngs_sh_gradient_from_views", "SH degree does not fit the coefficient count");
     if (P == 0) return 0;
@@ -620,7 +620,7 @@ extern "C" int ngs_idxmap_forward(int P, int M, int width, int height, const flo
     // accepted for signature parity with the reference, which does not read them either (rasterizer_impl.cu:851-984)
     (void)M; (void)normal; (void)scales; (void)rotations; (void)tan_fovx; (void)tan_fovy; (void)sh;
     if (num_rendered) *num_rendered = 0;
-    if (P < 0 || width <= 0 || height <= 0) return fail("ngs_idxmap_forward", "bad sizes");
+    if (P < 0 || P > NGS_MAX_GAUSSIANS || width <= 0 || height <= 0) return fail("ngs_idxmap_forward", "bad sizes");
     if (width > 32767 || height > 32767)
         return fail("ngs_idxmap_forward", "image too large (the reference walks pixels with 16-bit signed counters)");
     if (!out_idx || !out_color || !out_depth || !out_feature || !workspace)
@@ -653,7 +653,7 @@ extern "C" int ngs_idxmap_backward(int P, int width, int height, const float* me
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
     (void)campos;  // unused by the reference as well (rasterizer_impl.cu:820-847)
-    if (P < 0 || width <= 0 || height <= 0) return fail("ngs_idxmap_backward", "bad sizes");
+    if (P < 0 || P > NGS_MAX_GAUSSIANS || width <= 0 || height <= 0) return fail("ngs_idxmap_backward", "bad sizes");
     if (P == 0) return 0;
     if (!out_idx || !dL_dout_feature || !dL_dfeature_vector) return fail("ngs_idxmap_backward", "missing required pointer");
     if (((uintptr_t)dL_dout_feature | (uintptr_t)dL_dfeature_vector) % 16 != 0)
@@ -675,7 +675,7 @@ extern "C" int ngs_knn_mean_dist2(int P, const float* points, float* mean_dist2,
 {
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (P < 0) return fail("ngs_knn_mean_dist2", "bad sizes");
+    if (P < 0 || P > NGS_MAX_GAUSSIANS) return fail("ngs_knn_mean_dist2", "bad sizes");
     if (P == 0) return 0;
     if (!points || !mean_dist2 || !workspace) return fail("ngs_knn_mean_dist2", "missing required pointer");
     const int ps = prof_acquire();
@@ -694,7 +694,7 @@ extern "C" int ngs_sh_adam_from_views(int P, int D, int M, int V, const float* m
 {
     const char* fn = "ngs_sh_adam_from_views";
     g_err[0] = 0;
-    if (P < 0 || V < 1) return fail(fn, "bad sizes");
+    if (P < 0 || P > NGS_MAX_GAUSSIANS || V < 1) return fail(fn, "bad sizes");
     if (M != 16 || D < 0 || D > 3) return fail(fn, "the fused update needs rows of 16 coefficients and a degree of 0..3");
     if (P == 0) return 0;
     if (!means3D || !campos || !dL_dcolor_views || !shs || !sh_exp_avg || !sh_exp_avg_sq)

@@ -263,6 +263,18 @@ def test_prefiltered_with_culled_point_is_an_error(dgr):
         run_hip(dgr, c, prefiltered=True)
 
 
+def test_instance_count_beyond_int32_is_an_error(dgr):
+    """300 k Gaussians that each cover all 8160 tiles of a 1080p image would make 2.4e9 instances: the count is
+    handed on as a signed 32-bit number (the reference wraps around silently), so the call must fail -- and it does
+    so right after the scan, before anything is sized from the count."""
+    c = case(P=300_000, W=1920, H=1080, D=0, seed=3, log_scale=(2.5, 3.0), extent=(0.3, 0.3, 0.3))
+    with pytest.raises(RuntimeError, match="tile instances"):
+        run_hip(dgr, c)
+    # the library is usable afterwards
+    out = run_hip(dgr, case(P=100, W=32, H=32, D=0, seed=4))
+    assert out is not None
+
+
 def test_mark_visible(dgr, oracle):
     c = case(P=1000, W=64, H=64, D=0, seed=29, eye=(0.0, 0.0, -0.5))
     dev = torch.device("cuda:0")
