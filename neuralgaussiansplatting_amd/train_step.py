@@ -56,8 +56,8 @@ class GaussianTrainer:
     """Raw parameters, Adam state and the activated copies the rasterizer reads, all resident on one GPU.
 
     With a process group, every rank steps its own view and the gradients are averaged over the ranks' views before
-    Adam, so all ranks hold identical parameters.  The densification statistics are this rank's views only: sum
-    ``xyz_gradient_accum`` / ``denom`` and max-reduce ``max_radii2D`` over the ranks before densifying."""
+    Adam, so all ranks hold identical parameters.  The densification statistics are this rank's views only:
+    ``sync_densification_stats()`` merges them over the ranks before densifying."""
 
     def __init__(self, scene, device, opt=None, spatial_lr_scale=1.0, factored_exchange=True,
                  densify_stats=True):
@@ -94,6 +94,11 @@ class GaussianTrainer:
         self.densify_stats = densify_stats
         self._workspace = None
         self._dL_dpix = None
+
+    def sync_densification_stats(self, group=None):
+        """Totals over all ranks' views, in place (see ``view_parallel.sync_densification_stats``)."""
+        if self.densify_stats:
+            view_parallel.sync_densification_stats(self.xyz_gradient_accum, self.denom, self.max_radii2D, group)
 
     def scene_view(self):
         """The activated tensors in the shape ``view_parallel.forward_backward`` expects."""

@@ -197,6 +197,27 @@ class FactoredGradientExchange:
         return None
 
 
+def sync_densification_stats(xyz_gradient_accum, denom, max_radii2D, group=None):
+    """Merge the per-rank densification statistics in place, right before they are used: the view-space gradient
+    norms and the visibility counts (scene/gaussian_model.py:550-552) add up over the ranks' views, the largest
+    screen radius (train.py:115) is the maximum.  Afterwards every rank holds the totals over all views seen since
+    the last reset, so identical densification decisions follow; reset the statistics afterwards as the reference
+    does (gaussian_model.py:455-457) -- merging twice without a reset would count the views twice."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    sums = torch.cat([xyz_gradient_accum.reshape(-1), denom.reshape(-1)])
+    _all_reduce_sum(sums, group)
+    n = xyz_gradient_accum.numel()
+    xyz_gradient_accum.copy_(sums[:n].view_as(xyz_gradient_accum))
+    denom.copy_(sums[n:].view_as(denom))
+    if max_radii2D.is_cuda and dist.get_backend(group) != "nccl":
+        h = max_radii2D.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        max_radii2D.copy_(h)
+    else:
+        dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
+
+
 def shard_views(num_views, rank, world_size):
     """Indices of the views rank ``rank`` renders (round-robin)."""
     return list(range(rank, num_views, world_size))

@@ -103,6 +103,36 @@ def _factored_worker(rank, world, port, P, M, D, ret):
         dist.destroy_process_group()
 
 
+def _densify_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = 23
+        mk = lambda r: (torch.rand(P, 1, generator=torch.Generator().manual_seed(10 + r)),
+                        torch.randint(0, 5, (P, 1), generator=torch.Generator().manual_seed(20 + r)).float(),
+                        torch.randint(0, 90, (P,), generator=torch.Generator().manual_seed(30 + r), dtype=torch.int32))
+        acc, den, rad = mk(rank)
+        view_parallel.sync_densification_stats(acc, den, rad)
+        every = [mk(r) for r in range(world)]
+        ok = torch.equal(acc, sum(e[0] for e in every)) and torch.equal(den, sum(e[1] for e in every))
+        ok = ok and torch.equal(rad, torch.stack([e[2] for e in every]).max(dim=0).values)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_densification_stats_merge_world2():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_densify_worker, args=(2, 33700 + (os.getpid() % 2000), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
+    # without a process group it is a no-op
+    a, d, r = torch.ones(3, 1), torch.ones(3, 1), torch.ones(3, dtype=torch.int32)
+    view_parallel.sync_densification_stats(a, d, r)
+    assert a.sum() == 3 and r.sum() == 3
+
+
 def test_factored_exchange_world2():
     world, P, M, D = 2, 41, 16, 3
     mgr = mp.Manager()
