@@ -13,8 +13,14 @@
 
 #define SSIM_RADIUS 5
 #define SSIM_TAPS (2 * SSIM_RADIUS + 1)
-#define SSIM_TILE 16
-#define SSIM_EXT (SSIM_TILE + 2 * SSIM_RADIUS)  // 26: tile plus halo
+#define SSIM_TW 32                            // output tile of one workgroup: 32 x 32 pixels of one channel
+#define SSIM_TH 32
+#define SSIM_EW (SSIM_TW + 2 * SSIM_RADIUS)   // 42: tile plus halo
+#define SSIM_EH (SSIM_TH + 2 * SSIM_RADIUS)
+#define SSIM_SP (SSIM_EW + 1)                 // odd LDS pitches: lanes that differ in the row hit different banks
+#define SSIM_HP (SSIM_TW + 1)
+#define SSIM_HSPAN 8                          // horizontal pass: consecutive outputs per thread
+#define SSIM_VSPAN 4                          // vertical pass: consecutive output rows per thread
 #define SSIM_C1 (0.01f * 0.01f)
 #define SSIM_C2 (0.03f * 0.03f)
 
@@ -22,16 +28,67 @@ struct SsimWindow {
     float w[SSIM_TAPS];  // normalised 1-D Gaussian; the reference's 2-D window is its outer product
 };
 
-// Loads the SSIM_EXT x SSIM_EXT neighbourhood of tile (tx, ty) of one image plane into LDS, zeros outside the image
-// (the reference pads its convolutions with zeros).
-__device__ __forceinline__ void load_halo_tile(const float* __restrict__ plane, int W, int H, int tx, int ty,
-                                               float (*dst)[SSIM_EXT + 1], int tid)
+// The halo tile whose first output pixel is (x0, y0) travels from one image plane to LDS in two steps, so that a
+// kernel can request the tiles of all its planes before it waits for any of them: fetch_halo issues this thread's
+// global loads into registers (zeros outside the image: the reference pads its convolutions with zeros),
+// store_halo parks them in LDS.
+#define SSIM_HALO_PER_THREAD ((SSIM_EH * SSIM_EW + NGS_TILE_PIX - 1) / NGS_TILE_PIX)
+
+__device__ __forceinline__ void fetch_halo(const float* __restrict__ plane, int W, int H, int x0, int y0, int tid,
+                                           float (&v)[SSIM_HALO_PER_THREAD])
 {
-    for (int i = tid; i < SSIM_EXT * SSIM_EXT; i += NGS_TILE_PIX) {
-        const int r = i / SSIM_EXT, c = i - r * SSIM_EXT;
-        const int gx = tx * SSIM_TILE + c - SSIM_RADIUS, gy = ty * SSIM_TILE + r - SSIM_RADIUS;
-        dst[r][c] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? plane[(size_t)gy * W + gx] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < SSIM_HALO_PER_THREAD; k++) {
+        const int i = tid + k * NGS_TILE_PIX;
+        const int r = i / SSIM_EW, c = i - r * SSIM_EW;
+        const int gx = x0 + c - SSIM_RADIUS, gy = y0 + r - SSIM_RADIUS;
+        v[k] = (i < SSIM_EH * SSIM_EW && gx >= 0 && gx < W && gy >= 0 && gy < H) ? plane[(size_t)gy * W + gx] : 0.0f;
     }
+}
+
+__device__ __forceinline__ void store_halo(float (*dst)[SSIM_SP], int tid, const float (&v)[SSIM_HALO_PER_THREAD])
+{
+#pragma unroll
+    for (int k = 0; k < SSIM_HALO_PER_THREAD; k++) {
+        const int i = tid + k * NGS_TILE_PIX;
+        const int r = i / SSIM_EW, c = i - r * SSIM_EW;
+        if (i < SSIM_EH * SSIM_EW) dst[r][c] = v[k];
+    }
+}
+
+// Both blur passes keep a sliding window in registers: a thread of the horizontal pass reads 18 neighbours once and
+// produces 8 consecutive outputs of its row, a thread of the vertical pass reads 14 rows of its column and produces
+// 4, so each staged value is read from LDS 2-3 times instead of 11.
+//
+// Horizontal pass over the rows of the halo tile: work item (row r, group g) -> outputs hb[.][r][8g .. 8g+7].
+#define SSIM_HITEMS (SSIM_EH * (SSIM_TW / SSIM_HSPAN))
+
+// Vertical pass: K blurred values for the 4 output rows starting at row `ry` of column `lx`.
+template <int K>
+__device__ __forceinline__ void blur_columns(const float (*hb)[SSIM_EH][SSIM_HP], const SsimWindow& win, int lx, int ry,
+                                             float (*out)[SSIM_VSPAN])
+{
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int m = 0; m < K; m++) {
+        float col[SSIM_VSPAN + SSIM_TAPS - 1];
+#pragma unroll
+        for (int j = 0; j < SSIM_VSPAN + SSIM_TAPS - 1; j++) col[j] = hb[m][ry + j][lx];
+#pragma unroll
+        for (int o = 0; o < SSIM_VSPAN; o++) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < SSIM_TAPS; k++) a += win.w[k] * col[o + k];
+            out[m][o] = a;
+        }
+    }
+}
+
+__device__ __forceinline__ float fast_recip(float q)  // reciprocal refined by one Newton step (error below 1 ulp)
+{
+#pragma clang fp contract(fast)
+    const float x = __builtin_amdgcn_rcpf(q);
+    return x * (2.0f - q * x);
 }
 
 // Pass 1: SSIM map, L1 term and the three per-pixel partial derivatives of the SSIM value wrt the blurred maps
@@ -41,72 +98,91 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void ssim_l1_forward_kernel(
     float* __restrict__ d_mu1, float* __restrict__ d_e1, float* __restrict__ d_e12, float* __restrict__ partial_sums)
 {
 #pragma clang fp contract(fast)  // the blurs are FMA chains; nothing here has to match another evaluation bit for bit
-    __shared__ float sx[SSIM_EXT][SSIM_EXT + 1], sy[SSIM_EXT][SSIM_EXT + 1];
-    __shared__ float hb[5][SSIM_EXT][SSIM_TILE];
+    __shared__ float sx[SSIM_EH][SSIM_SP], sy[SSIM_EH][SSIM_SP];
+    __shared__ float hb[5][SSIM_EH][SSIM_HP];
     __shared__ float red[2][NGS_TILE_PIX / 64];
     const int tid = threadIdx.x;
-    const int tiles_x = (W + SSIM_TILE - 1) / SSIM_TILE;
+    const int tiles_x = (W + SSIM_TW - 1) / SSIM_TW;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, ch = blockIdx.y;
+    const int x0 = tx * SSIM_TW, y0 = ty * SSIM_TH;
     const size_t plane = (size_t)W * H;
-    load_halo_tile(img + ch * plane, W, H, tx, ty, sx, tid);
-    load_halo_tile(gt + ch * plane, W, H, tx, ty, sy, tid);
+    {
+        float vx[SSIM_HALO_PER_THREAD], vy[SSIM_HALO_PER_THREAD];
+        fetch_halo(img + ch * plane, W, H, x0, y0, tid, vx);
+        fetch_halo(gt + ch * plane, W, H, x0, y0, tid, vy);
+        store_halo(sx, tid, vx);
+        store_halo(sy, tid, vy);
+    }
     __syncthreads();
     // horizontal blur of x, y, x^2, y^2, xy for every row of the halo tile
-    for (int i = tid; i < SSIM_EXT * SSIM_TILE; i += NGS_TILE_PIX) {
-        const int r = i / SSIM_TILE, c = i - r * SSIM_TILE;
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    if (tid < SSIM_HITEMS) {
+        const int g = tid / SSIM_EH, r = tid - g * SSIM_EH, c0 = g * SSIM_HSPAN;
+        float xs[SSIM_HSPAN + SSIM_TAPS - 1], ys[SSIM_HSPAN + SSIM_TAPS - 1], xx[SSIM_HSPAN + SSIM_TAPS - 1],
+            yy[SSIM_HSPAN + SSIM_TAPS - 1], xy[SSIM_HSPAN + SSIM_TAPS - 1];
 #pragma unroll
-        for (int k = 0; k < SSIM_TAPS; k++) {
-            const float x = sx[r][c + k], y = sy[r][c + k], w = win.w[k];
-            a0 += w * x;
-            a1 += w * y;
-            a2 += w * (x * x);
-            a3 += w * (y * y);
-            a4 += w * (x * y);
+        for (int j = 0; j < SSIM_HSPAN + SSIM_TAPS - 1; j++) {
+            xs[j] = sx[r][c0 + j];
+            ys[j] = sy[r][c0 + j];
+            xx[j] = xs[j] * xs[j];
+            yy[j] = ys[j] * ys[j];
+            xy[j] = xs[j] * ys[j];
         }
-        hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2; hb[3][r][c] = a3; hb[4][r][c] = a4;
+#pragma unroll
+        for (int o = 0; o < SSIM_HSPAN; o++) {
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+            for (int k = 0; k < SSIM_TAPS; k++) {
+                const float w = win.w[k];
+                a0 += w * xs[o + k];
+                a1 += w * ys[o + k];
+                a2 += w * xx[o + k];
+                a3 += w * yy[o + k];
+                a4 += w * xy[o + k];
+            }
+            hb[0][r][c0 + o] = a0; hb[1][r][c0 + o] = a1; hb[2][r][c0 + o] = a2; hb[3][r][c0 + o] = a3;
+            hb[4][r][c0 + o] = a4;
+        }
     }
     __syncthreads();
-    const int lx = tid & (SSIM_TILE - 1), ly = tid / SSIM_TILE;
-    const int gx = tx * SSIM_TILE + lx, gy = ty * SSIM_TILE + ly;
-    float s_val = 0.0f, l1_val = 0.0f;
-    if (gx < W && gy < H) {
-        float mu1 = 0, mu2 = 0, e1 = 0, e2 = 0, e12 = 0;
+    const int lx = tid & (SSIM_TW - 1), ry = (tid / SSIM_TW) * SSIM_VSPAN;
+    float b[5][SSIM_VSPAN];
+    blur_columns<5>(hb, win, lx, ry, b);
+    const int gx = x0 + lx;
+    float s_sum = 0.0f, l1_sum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < SSIM_TAPS; k++) {
-            const float w = win.w[k];
-            mu1 += w * hb[0][ly + k][lx];
-            mu2 += w * hb[1][ly + k][lx];
-            e1 += w * hb[2][ly + k][lx];
-            e2 += w * hb[3][ly + k][lx];
-            e12 += w * hb[4][ly + k][lx];
+    for (int o = 0; o < SSIM_VSPAN; o++) {
+        const int gy = y0 + ry + o;
+        if (gx < W && gy < H) {
+            const float mu1 = b[0][o], mu2 = b[1][o], e1 = b[2][o], e2 = b[3][o], e12 = b[4][o];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float sigma1 = e1 - mu1_sq, sigma2 = e2 - mu2_sq, sigma12 = e12 - mu12;
+            const float n1 = 2.0f * mu12 + SSIM_C1, n2 = 2.0f * sigma12 + SSIM_C2;
+            const float q1 = mu1_sq + mu2_sq + SSIM_C1, q2 = sigma1 + sigma2 + SSIM_C2;
+            const float inv2 = fast_recip(q2);
+            const float inv = fast_recip(q1) * inv2;
+            const float s_val = (n1 * n2) * inv;
+            // d/d(mu1) with E1, E12 fixed: n1' = 2 mu2, n2' = -2 mu2, q1' = 2 mu1, q2' = -2 mu1
+            const float dnum = 2.0f * mu2 * (n2 - n1);
+            const float dden = 2.0f * mu1 * (q2 - q1);
+            const size_t p = ch * plane + (size_t)gy * W + gx;
+            d_mu1[p] = (dnum - s_val * dden) * inv;
+            d_e1[p] = -s_val * inv2;
+            d_e12[p] = 2.0f * n1 * inv;
+            s_sum += s_val;
+            l1_sum += fabsf(sx[ry + o + SSIM_RADIUS][lx + SSIM_RADIUS] - sy[ry + o + SSIM_RADIUS][lx + SSIM_RADIUS]);
         }
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float sigma1 = e1 - mu1_sq, sigma2 = e2 - mu2_sq, sigma12 = e12 - mu12;
-        const float n1 = 2.0f * mu12 + SSIM_C1, n2 = 2.0f * sigma12 + SSIM_C2;
-        const float q1 = mu1_sq + mu2_sq + SSIM_C1, q2 = sigma1 + sigma2 + SSIM_C2;
-        const float inv = 1.0f / (q1 * q2);
-        s_val = (n1 * n2) * inv;
-        // d/d(mu1) with E1, E12 fixed: n1' = 2 mu2, n2' = -2 mu2, q1' = 2 mu1, q2' = -2 mu1
-        const float dnum = 2.0f * mu2 * (n2 - n1);
-        const float dden = 2.0f * mu1 * (q2 - q1);
-        const size_t p = ch * plane + (size_t)gy * W + gx;
-        d_mu1[p] = (dnum - s_val * dden) * inv;
-        d_e1[p] = -s_val / q2;
-        d_e12[p] = 2.0f * n1 * inv;
-        l1_val = fabsf(sx[ly + SSIM_RADIUS][lx + SSIM_RADIUS] - sy[ly + SSIM_RADIUS][lx + SSIM_RADIUS]);
     }
     // block sums, in a fixed order (the final reduction is a single block as well: the loss value is deterministic)
-    const float ws = wave_sum_lane63(s_val), wl = wave_sum_lane63(l1_val);
+    const float ws = wave_sum_lane63(s_sum), wl = wave_sum_lane63(l1_sum);
     if ((tid & 63) == 63) {
         red[0][tid >> 6] = ws;
         red[1][tid >> 6] = wl;
     }
     __syncthreads();
     if (tid == 0) {
-        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        partial_sums[2 * b] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        partial_sums[2 * b + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const size_t bi = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partial_sums[2 * bi] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial_sums[2 * bi + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
@@ -150,44 +226,53 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void ssim_l1_backward_kernel(
     float c_ssim, float* __restrict__ dL_dimg)
 {
 #pragma clang fp contract(fast)
-    __shared__ float sp[3][SSIM_EXT][SSIM_EXT + 1];
-    __shared__ float hb[3][SSIM_EXT][SSIM_TILE];
+    __shared__ float sp[3][SSIM_EH][SSIM_SP];
+    __shared__ float hb[3][SSIM_EH][SSIM_HP];
     const int tid = threadIdx.x;
-    const int tiles_x = (W + SSIM_TILE - 1) / SSIM_TILE;
+    const int tiles_x = (W + SSIM_TW - 1) / SSIM_TW;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, ch = blockIdx.y;
+    const int x0 = tx * SSIM_TW, y0 = ty * SSIM_TH;
     const size_t plane = (size_t)W * H;
-    load_halo_tile(d_mu1 + ch * plane, W, H, tx, ty, sp[0], tid);
-    load_halo_tile(d_e1 + ch * plane, W, H, tx, ty, sp[1], tid);
-    load_halo_tile(d_e12 + ch * plane, W, H, tx, ty, sp[2], tid);
-    __syncthreads();
-    for (int i = tid; i < SSIM_EXT * SSIM_TILE; i += NGS_TILE_PIX) {
-        const int r = i / SSIM_TILE, c = i - r * SSIM_TILE;
-        float a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-        for (int k = 0; k < SSIM_TAPS; k++) {
-            const float w = win.w[k];
-            a0 += w * sp[0][r][c + k];
-            a1 += w * sp[1][r][c + k];
-            a2 += w * sp[2][r][c + k];
-        }
-        hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2;
+    {
+        float v0[SSIM_HALO_PER_THREAD], v1[SSIM_HALO_PER_THREAD], v2[SSIM_HALO_PER_THREAD];
+        fetch_halo(d_mu1 + ch * plane, W, H, x0, y0, tid, v0);
+        fetch_halo(d_e1 + ch * plane, W, H, x0, y0, tid, v1);
+        fetch_halo(d_e12 + ch * plane, W, H, x0, y0, tid, v2);
+        store_halo(sp[0], tid, v0);
+        store_halo(sp[1], tid, v1);
+        store_halo(sp[2], tid, v2);
     }
     __syncthreads();
-    const int lx = tid & (SSIM_TILE - 1), ly = tid / SSIM_TILE;
-    const int gx = tx * SSIM_TILE + lx, gy = ty * SSIM_TILE + ly;
-    if (gx < W && gy < H) {
-        float b0 = 0, b1 = 0, b2 = 0;
+    if (tid < SSIM_HITEMS) {
+        const int g = tid / SSIM_EH, r = tid - g * SSIM_EH, c0 = g * SSIM_HSPAN;
 #pragma unroll
-        for (int k = 0; k < SSIM_TAPS; k++) {
-            const float w = win.w[k];
-            b0 += w * hb[0][ly + k][lx];
-            b1 += w * hb[1][ly + k][lx];
-            b2 += w * hb[2][ly + k][lx];
+        for (int m = 0; m < 3; m++) {
+            float v[SSIM_HSPAN + SSIM_TAPS - 1];
+#pragma unroll
+            for (int j = 0; j < SSIM_HSPAN + SSIM_TAPS - 1; j++) v[j] = sp[m][r][c0 + j];
+#pragma unroll
+            for (int o = 0; o < SSIM_HSPAN; o++) {
+                float a = 0.0f;
+#pragma unroll
+                for (int k = 0; k < SSIM_TAPS; k++) a += win.w[k] * v[o + k];
+                hb[m][r][c0 + o] = a;
+            }
         }
-        const size_t p = ch * plane + (size_t)gy * W + gx;
-        const float x = img[p], y = gt[p], d = x - y;
-        const float sgn = d > 0.0f ? 1.0f : d < 0.0f ? -1.0f : 0.0f;
-        dL_dimg[p] = c_l1 * sgn - c_ssim * (b0 + 2.0f * x * b1 + y * b2);
+    }
+    __syncthreads();
+    const int lx = tid & (SSIM_TW - 1), ry = (tid / SSIM_TW) * SSIM_VSPAN;
+    float b[3][SSIM_VSPAN];
+    blur_columns<3>(hb, win, lx, ry, b);
+    const int gx = x0 + lx;
+#pragma unroll
+    for (int o = 0; o < SSIM_VSPAN; o++) {
+        const int gy = y0 + ry + o;
+        if (gx < W && gy < H) {
+            const size_t p = ch * plane + (size_t)gy * W + gx;
+            const float x = img[p], y = gt[p], d = x - y;
+            const float sgn = d > 0.0f ? 1.0f : d < 0.0f ? -1.0f : 0.0f;
+            dL_dimg[p] = c_l1 * sgn - c_ssim * (b[0][o] + 2.0f * x * b[1][o] + y * b[2][o]);
+        }
     }
 }
 
@@ -338,7 +423,7 @@ static SsimWindow make_window()
 
 size_t ngs_loss_workspace_floats(int W, int H)
 {
-    const size_t tiles = (size_t)((W + SSIM_TILE - 1) / SSIM_TILE) * ((H + SSIM_TILE - 1) / SSIM_TILE);
+    const size_t tiles = (size_t)((W + SSIM_TW - 1) / SSIM_TW) * ((H + SSIM_TH - 1) / SSIM_TH);
     return 9 * (size_t)W * H + 2 + 2 * 3 * tiles;  // +2: the block sums start on an 8-byte boundary
 }
 
@@ -351,7 +436,7 @@ void ngs_launch_l1_ssim(hipStream_t s, int W, int H, float lambda_dssim, const f
     float* d_e1 = workspace + n;
     float* d_e12 = workspace + 2 * n;
     float* partial = workspace + ((3 * n + 1) & ~(size_t)1);  // read back as float2
-    const int tiles = ((W + SSIM_TILE - 1) / SSIM_TILE) * ((H + SSIM_TILE - 1) / SSIM_TILE);
+    const int tiles = ((W + SSIM_TW - 1) / SSIM_TW) * ((H + SSIM_TH - 1) / SSIM_TH);
     hipLaunchKernelGGL(ssim_l1_forward_kernel, dim3(tiles, 3), dim3(NGS_TILE_PIX), 0, s, W, H, win, img, gt, d_mu1,
                        d_e1, d_e12, partial);
     const float inv_count = (float)(1.0 / (double)n);

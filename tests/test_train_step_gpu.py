@@ -37,7 +37,7 @@ def test_fused_loss_matches_reference_fixture(C):
     assert float(np.abs(dL.cpu().numpy() - g).max()) <= 1e-4 * float(np.abs(g).max())
 
 
-@pytest.mark.parametrize("H,W", [(16, 16), (7, 5), (64, 48), (33, 130)])
+@pytest.mark.parametrize("H,W", [(16, 16), (7, 5), (64, 48), (33, 130), (75, 41)])
 def test_fused_loss_matches_torch_formulation(C, H, W):
     g = torch.Generator().manual_seed(H * 1000 + W)
     img = torch.rand(3, H, W, generator=g).to(DEV).requires_grad_(True)
