@@ -117,6 +117,18 @@ def test_forward_backward_matches_oracle(name, dgr, oracle):
     check_grads(h["grads"], og, scale=float(c["W"] * c["H"]))
 
 
+def test_more_than_65536_tiles(dgr, oracle):
+    """4112 x 4112 pixels = 257 x 257 tiles: tile ids need 17 bits, so the global part of the sort runs three radix
+    passes (the other cases run one or two) and the tile coordinates use the upper range of their 16-bit fields."""
+    c = case(P=2000, W=4112, H=4112, D=0, log_scale=(-4.2, -3.2), seed=41)
+    dL = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(5))
+    o = oracle_forward(oracle, c)
+    assert o["ranges"].shape[0] == 257 * 257 and o["point_list"].size > 100000
+    h = run_hip(dgr, c, dL_dpix=dL)
+    check_forward(o, h)
+    check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=float(c["W"] * c["H"]))
+
+
 def test_culled_and_offscreen_gaussians(dgr, oracle):
     c = case(P=500, W=64, H=64, D=0, seed=21, eye=(0.0, 0.0, -0.6), extent=(1.5, 1.5, 1.3))
     o = oracle_forward(oracle, c)
