@@ -1,0 +1,28 @@
+#!/bin/bash
+# Regenerates the measurements kept under profiles/ on a GPU box: bench lines for every configuration, the
+# rocprofv3 kernel statistics of the default bench, and the three counter passes.  Each GPU step runs under its
+# own time limit; the script stops at the first failure.  Usage (from the repository root): bash tools/collect_profiles.sh
+set -e -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/final
+mkdir -p $OUT
+cd $ROOT
+for c in c4 c1 c2 c3 c5; do
+    timeout -k 10 300 python3 bench.py --config $c > $OUT/${c}_bench.json 2> $OUT/${c}_bench.err
+    echo "bench $c done"
+done
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29671 \
+    bench.py --gpus 2 --steps 5 --warmup 1 --backend gloo --no-idxmap 2> $OUT/gloo2.err | grep '"metric"' > $OUT/c4_gloo2_rehearsal.json
+echo "gloo rehearsal done"
+cd /tmp
+export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
+echo "trace done"
+PMC_CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --train-steps 0 --no-idxmap --no-cpu-baseline"
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMC_CMD > $OUT/pmc_fetch.log 2>&1
+echo "fetch done"
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PMC_CMD > $OUT/pmc_write.log 2>&1
+echo "write done"
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+    --output-format csv -d $OUT/pmc_valu -- $PMC_CMD > $OUT/pmc_valu.log 2>&1
+echo "valu done"
