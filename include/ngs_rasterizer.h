@@ -246,7 +246,7 @@ int ngs_knn_mean_dist2(int P, const float* points, float* mean_dist2, char* work
  *                internal_radii(i32), clamped_bits(u8), block_sums(u32),
  *                block_offsets(u32), misc(u32[8]), grad_accumulator(float[16])
  *  binning[2]:   sorted_keys(u64), point_list(u32)   (the unsorted pairs do not survive the sort's ping-pong)
- *  image[3]:     final_T(float, per tile in thread order: [tile][2x2 blocks][8][8]), n_contrib(u32, tile-major), ranges(uint2[tiles])
+ *  image[3]:     final_T(float, per tile in thread order: [tile][2x2 blocks][2x2 quadrants][4][4]), n_contrib(u32, tile-major), ranges(uint2[tiles])
  * No counterpart in the reference (its state structs are private, rasterizer_impl.h:29-65).
  */
 int ngs_state_layout(int P, long long R, int width, int height, size_t* geometry, size_t* binning, size_t* image);

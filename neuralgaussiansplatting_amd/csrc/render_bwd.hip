@@ -6,55 +6,46 @@
 //    the per-pixel last-contributor indices the forward pass stored) instead
 //    of at the end of the tile's list: entries behind it are skipped by every
 //    pixel in the reference too (backward.cu:486-488), so they are never staged.
-//  * Each wave ballots which staged splats can reach its 8x8 block AND lie in
-//    front of the block's own deepest contributor, and walks only those.
+//  * Every 16-lane row of a wave owns one 4x4 pixel quadrant and walks its OWN
+//    list of splats: per batch of staged splats each wave ballots, quadrant by
+//    quadrant, which splats can reach the quadrant and lie in front of its
+//    deepest contributor, compacts the survivors into four short index lists,
+//    and then all four rows step through their lists side by side.  A small
+//    quadrant is touched by far fewer splats than a tile, and a touching splat
+//    covers most of its pixels, so few lanes run the arithmetic for nothing.
 //  * Reduction: the reference issues nine global float atomics per (pixel,
-//    splat) pair.  Here all 64 lanes of a wave handle the same splat in
-//    lock-step, so the nine partials are summed across the wave in registers
-//    (lane-half / row swaps + DPP row shifts, a reduce-scatter), then
-//    across the tile's four waves in an LDS table holding one row per staged
-//    splat, and each splat's row leaves the workgroup once per batch as ONE
-//    64-byte-row group of global atomics into the [P][16] accumulator.
+//    splat) pair.  Here the nine partials are summed over the 16 pixels of the
+//    quadrant in registers (a reduce-scatter of DPP row exchanges: after four
+//    steps nine lanes of the row hold one total each), then across quadrants
+//    and waves in an LDS table holding one row per staged splat, and each
+//    splat's row leaves the workgroup once per batch as ONE 64-byte-row group
+//    of global atomics into the [P][16] accumulator.
 #include "render_common.h"
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // pairs of channels go through the packed-FP32 instructions
 
-// [a summed over lane pairs (l, l+32) in lanes 0-31 | b likewise in lanes 32-63]
-__device__ __forceinline__ float fold32(float a, float b)
+// One step of the reduce-scatter inside a 16-lane row.  `ctrl` is a DPP pattern that pairs every lane with a lane
+// whose `upper` flag is the opposite; afterwards the lanes with upper == false hold a summed over each pair, the
+// others b.
+template <int ctrl>
+__device__ __forceinline__ float row_fold(float a, float b, bool upper)
 {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
-                                                    false, false);
-    unsigned x = r[0], y = r[1];
-    // hipcc (ROCm 7.2) folds "r[0] + r[1]" of a lane swap into "r[0] + r[0]"; an opaque use of the second result
-    // keeps the two registers apart.
-    asm volatile("" : "+v"(y));
-    return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+    const float keep = upper ? b : a, give = upper ? a : b;
+    return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), ctrl, 0xf,
+                                                                        0xf, false));
 }
+template <int ctrl>
+__device__ __forceinline__ float row_pair_sum(float a)
+{
+    return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), ctrl, 0xf, 0xf,
+                                                                     false));
+}
+#define DPP_ROW_MIRROR 0x140       // lane i <-> 15 - i
+#define DPP_ROW_HALF_MIRROR 0x141  // lane i <-> 7 - i inside each half row
+#define DPP_QUAD_XOR2 0x4E         // quad_perm [2,3,0,1]
+#define DPP_QUAD_XOR1 0xB1         // quad_perm [1,0,3,2]
 
-// rows 0,2: a summed over row pairs (0,1) / (2,3); rows 1,3: b likewise
-__device__ __forceinline__ float fold16(float a, float b)
-{
-    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
-                                                    false, false);
-    unsigned x = r[0], y = r[1];
-    // hipcc (ROCm 7.2) folds "r[0] + r[1]" of a lane swap into "r[0] + r[0]"; an opaque use of the second result
-    // keeps the two registers apart.
-    asm volatile("" : "+v"(y));
-    return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
-}
-
-// Sum over each 16-lane row; valid in lane 15 of the row.
-__device__ __forceinline__ float row_sum_lane15(float v)
-{
-#define NGS_ROW_ADD(ctrl) \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
-    NGS_ROW_ADD(0x111);  // row_shr:1
-    NGS_ROW_ADD(0x112);  // row_shr:2
-    NGS_ROW_ADD(0x114);  // row_shr:4
-    NGS_ROW_ADD(0x118);  // row_shr:8
-#undef NGS_ROW_ADD
-    return v;
-}
+#define BWD_BATCH NGS_TILE_PIX  // splats staged per round
 
 __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
@@ -62,27 +53,35 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     const float* __restrict__ dL_dpix, float* __restrict__ acc)
 {
     // record k: [0] = {x, y, ln(255 opacity), -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
-    __shared__ float4 s_rec[NGS_TILE_PIX][3];
-    __shared__ float s_acc[NGS_TILE_PIX][ACC_USED];
+    __shared__ float4 s_rec[BWD_BATCH][3];
+    __shared__ float s_acc[BWD_BATCH][ACC_USED];
+    __shared__ uint8_t s_list[NGS_TILE_PIX / 64][4][BWD_BATCH];  // per wave and quadrant: staged slots to visit
     __shared__ uint32_t s_wmax[NGS_TILE_PIX / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane >> 4, li = lane & 15;
     const int tile = blockIdx.x;
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int px = tx * NGS_TILE_W + tile_local_x(tid), py = ty * NGS_TILE_H + tile_local_y(tid);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const float sx0 = (float)(tx * NGS_TILE_W + (wave & 1) * NGS_WAVE_W), sx1 = sx0 + (NGS_WAVE_W - 1);
-    const float sy0 = (float)(ty * NGS_TILE_H + (wave >> 1) * NGS_WAVE_H), sy1 = sy0 + (NGS_WAVE_H - 1);
+    // corner pixel of this wave's 8x8 block; quadrant k spans [bx0 + 4 (k & 1), +3] x [by0 + 4 (k >> 1), +3]
+    const float bx0 = (float)(tx * NGS_TILE_W + (wave & 1) * NGS_WAVE_W);
+    const float by0 = (float)(ty * NGS_TILE_H + (wave >> 1) * NGS_WAVE_H);
     const uint2 range = ranges[tile];
 
     const size_t tp = (size_t)tile * NGS_TILE_PIX + tid;
     const float T_final = inside ? final_T[tp] : 0.0f;
     float T = T_final;
     const uint32_t last_contributor = inside ? n_contrib[tp] : 0u;
-    // deepest contributor of this block (wave) and of the tile
-    uint32_t wmax = last_contributor;
+    // deepest contributor of each quadrant (16-lane row), of this block (wave) and of the tile
+    uint32_t qmax = last_contributor;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o, 64));
+    for (int o = 8; o > 0; o >>= 1) qmax = max(qmax, (uint32_t)__shfl_xor((int)qmax, o, 64));
+    const uint32_t qmax0 = (uint32_t)__builtin_amdgcn_readlane((int)qmax, 0);
+    const uint32_t qmax1 = (uint32_t)__builtin_amdgcn_readlane((int)qmax, 16);
+    const uint32_t qmax2 = (uint32_t)__builtin_amdgcn_readlane((int)qmax, 32);
+    const uint32_t qmax3 = (uint32_t)__builtin_amdgcn_readlane((int)qmax, 48);
+    const uint32_t wmax = max(max(qmax0, qmax1), max(qmax2, qmax3));
     if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
     const uint32_t tmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
@@ -104,19 +103,19 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     const v2f dp_rg = {dpr, dpg};
     const v2f ddel = {(float)(0.5 * W), (float)(0.5 * H)};  // d(pixel offset)/d(ndc)
     const v2f pix = {pxf, pyf};
-    // accumulator slots this lane's 16-lane row ends up holding after the reduce-scatter below
-    const int lrow = lane >> 4;
-    const int slot0 = lrow == 0 ? ACC_DX : lrow == 1 ? ACC_CON_B : lrow == 2 ? ACC_OPAC : ACC_B;
-    const int slot1 = lrow == 0 ? ACC_DY : lrow == 1 ? ACC_CON_C : lrow == 2 ? ACC_R : -1;
-    const int slot2 = lrow == 0 ? ACC_CON_A : lrow == 2 ? ACC_G : -1;
+    // After the reduce-scatter the even lanes of a row hold partials 0..7 (index bits taken from lane bits 3, 2, 1
+    // in that order of significance 1, 2, 4) and the odd lanes partial 8; lane 1 speaks for the odd ones.
+    const bool up8 = (li & 8) != 0, up4 = (li & 4) != 0, up2 = (li & 2) != 0, up1 = (li & 1) != 0;
+    const int my_slot = !up1 ? ((up2 ? 4 : 0) + (up4 ? 2 : 0) + (up8 ? 1 : 0)) : (li == 1 ? 8 : -1);
+    uint8_t* const my_list = &s_list[wave][row][0];
 
-    // Zero-based list positions tmax-1 ... 0 are walked in that order, 256 per batch;
-    // staged slot s of batch r holds list position tmax-1 - r*256 - s.
-    const int rounds = (int)((tmax + NGS_TILE_PIX - 1) / NGS_TILE_PIX);
+    // Zero-based list positions tmax-1 ... 0 are walked in that order, BWD_BATCH per round;
+    // staged slot s of round r holds list position tmax-1 - r*BWD_BATCH - s.
+    const int rounds = (int)((tmax + BWD_BATCH - 1) / BWD_BATCH);
     for (int r = 0; r < rounds; r++) {
         __syncthreads();  // previous batch fully flushed before its LDS is reused
-        const int first = (int)tmax - 1 - r * NGS_TILE_PIX;  // list position of slot 0
-        const int nb = min(NGS_TILE_PIX, first + 1);
+        const int first = (int)tmax - 1 - r * BWD_BATCH;  // list position of slot 0
+        const int nb = min(BWD_BATCH, first + 1);
         if (tid < nb) {
             const uint32_t id = plist[range.x + (uint32_t)(first - tid)];
             const float4* gr = splat_rec + 4 * (size_t)id;  // one 64-byte line per splat
@@ -130,89 +129,115 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
 #pragma unroll
         for (int c = 0; c < ACC_USED; c++) s_acc[tid][c] = 0.0f;
         __syncthreads();
+
+        // ---- which staged splats does each quadrant of this block have to visit? ----
+        int n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // wave-uniform list lengths
         for (int chunk = 0; chunk < nb; chunk += 64) {
             const int mine = chunk + lane;
-            bool reach = false;
-            if (mine < nb && (uint32_t)(first - mine) < wmax) {
+            bool r0 = false, r1 = false, r2 = false, r3 = false;
+            if (mine < nb) {
+                const uint32_t pos = (uint32_t)(first - mine);
                 const float4 p = s_rec[mine][0];
                 const float4 q = s_rec[mine][1];
-                reach = splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, sx0, sx1, sy0, sy1);
+                r0 = pos < qmax0 && splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, bx0, bx0 + 3.0f, by0, by0 + 3.0f);
+                r1 = pos < qmax1 && splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, bx0 + 4.0f, bx0 + 7.0f, by0, by0 + 3.0f);
+                r2 = pos < qmax2 && splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, bx0, bx0 + 3.0f, by0 + 4.0f, by0 + 7.0f);
+                r3 = pos < qmax3 &&
+                     splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, bx0 + 4.0f, bx0 + 7.0f, by0 + 4.0f, by0 + 7.0f);
             }
-            unsigned long long mask = __ballot(reach);
-            while (mask) {
-                const int j = chunk + lowest_lane(mask);
-                mask &= mask - 1ull;
-                const uint32_t pos = (uint32_t)(first - j);  // the reference's `contributor` after its decrement
-                const float4 p = s_rec[j][0];
-                const float4 q = s_rec[j][1];
-                const float4 col = s_rec[j][2];
-                const v2f d = (v2f){p.x, p.y} - pix;  // {dx, dy}
-                const float dx = d.x, dy = d.y;
-                // same evaluation order as the forward pass (and the reference): alpha must come out bit-identical
-                const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
-                const float G = exp_nonpos(power);
-                const float alpha = fminf(0.99f, q.w * G);
-                const bool live = pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__ballot(live) == 0ull) continue;  // wave-uniform
+            const unsigned long long m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (r0) s_list[wave][0][n0 + __popcll(m0 & below)] = (uint8_t)mine;
+            if (r1) s_list[wave][1][n1 + __popcll(m1 & below)] = (uint8_t)mine;
+            if (r2) s_list[wave][2][n2 + __popcll(m2 & below)] = (uint8_t)mine;
+            if (r3) s_list[wave][3][n3 + __popcll(m3 & below)] = (uint8_t)mine;
+            n0 += __popcll(m0);
+            n1 += __popcll(m1);
+            n2 += __popcll(m2);
+            n3 += __popcll(m3);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int my_n = row == 0 ? n0 : row == 1 ? n1 : row == 2 ? n2 : n3;
+        const int steps = max(max(n0, n1), max(n2, n3));
 
-                // Every lane evaluates the body.  A dead lane (pixel that does not blend this splat) runs it with
-                // alpha = 0, which leaves its state untouched without a single select: T / (1 - 0) = T, the
-                // colour behind it becomes 0 * colour + 1 * rec = rec, and every partial below is an exact zero
-                // (G and dL/dalpha are forced to 0 as well).
-                const float alpha_l = live ? alpha : 0.0f;
-                const float om = 1.f - alpha_l;
-                const float inv = __builtin_amdgcn_rcpf(om);  // v_rcp_f32, 1 ulp; exactly 1 for a dead lane
-                const float Tn = T * inv;
-                const float w = alpha_l * Tn;
-                const v2f col_rg = {col.x, col.y};
-                // `rec` is the colour accumulated behind this splat (the reference's accum_rec after its update,
-                // backward.cu:503-513)
-                const v2f d_rg = (col_rg - rec_rg) * dp_rg;
-                float dL_dalpha = d_rg.x + d_rg.y;
-                dL_dalpha += (col.z - rec_b) * dpb;
-                dL_dalpha *= Tn;
-                dL_dalpha += (-T_final * inv) * bgdot;
-                dL_dalpha = live ? dL_dalpha : 0.0f;
-                const float Gl = live ? G : 0.0f;
-                const float dL_dG = q.w * dL_dalpha;
-                const v2f gd = Gl * d;  // {G dx, G dy}
-                const v2f gx = {gd.x, gd.x}, gy = {gd.y, gd.y};
-                // {dG/ddelx, dG/ddely} = -gdx * {a, b} - gdy * {b, c}
-                const v2f dG = -gx * (v2f){q.x, q.y} - gy * (v2f){q.y, q.z};
-                const v2f v01 = (dL_dG * dG) * ddel;            // ACC_DX, ACC_DY
-                const float v0 = v01.x, v1 = v01.y;
-                const v2f h = -0.5f * gd;
-                const v2f v23 = ((v2f){h.x, h.x} * d) * dL_dG;  // ACC_CON_A, ACC_CON_B
-                const float v2 = v23.x, v3 = v23.y;
-                const float v4 = h.y * dy * dL_dG;              // ACC_CON_C
-                const float v5 = Gl * dL_dalpha;                // ACC_OPAC
-                const v2f v67 = w * dp_rg;                      // ACC_R, ACC_G
-                const float v6 = v67.x, v7 = v67.y;
-                const float v8 = w * dpb;                       // ACC_B
-                // state for the next (nearer) splat: transmittance in front of this one, and the colour behind
-                // the next one = this splat blended over what was behind it (same expression the reference
-                // evaluates one step later from its last_alpha / last_color)
-                T = Tn;
-                rec_rg = alpha_l * col_rg + om * rec_rg;
-                rec_b = alpha_l * col.z + om * rec_b;
+        // ---- the four rows walk their lists side by side ----
+        // The records of the next step are requested before the arithmetic of the current one, so the LDS round
+        // trips (list entry, then record) overlap with it.
+        int j_next = 0 < my_n ? (int)my_list[0] : 0;
+        float4 p_next = s_rec[j_next][0], q_next = s_rec[j_next][1], col_next = s_rec[j_next][2];
+        int j_after = 1 < my_n ? (int)my_list[1] : 0;
+        for (int it = 0; it < steps; it++) {
+            const bool have = it < my_n;
+            const int j = j_next;
+            const float4 p = p_next, q = q_next, col = col_next;
+            j_next = j_after;
+            p_next = s_rec[j_next][0];
+            q_next = s_rec[j_next][1];
+            col_next = s_rec[j_next][2];
+            j_after = it + 2 < my_n ? (int)my_list[it + 2] : 0;
+            const uint32_t pos = (uint32_t)(first - j);  // the reference's `contributor` after its decrement
+            const v2f d = (v2f){p.x, p.y} - pix;  // {dx, dy}
+            const float dx = d.x, dy = d.y;
+            // same evaluation order as the forward pass (and the reference): alpha must come out bit-identical
+            const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
+            const float G = exp_nonpos(power);
+            const float alpha = fminf(0.99f, q.w * G);
+            const bool live = have && pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (__ballot(live) == 0ull) continue;  // wave-uniform
 
-                // Wave reduction of the nine partials as a reduce-scatter: two half/row swaps fold the 64 lanes
-                // into 16 columns while spreading the nine values over the four 16-lane rows of three registers,
-                // then one 4-step DPP row reduction per register leaves each value's total in lane 15 of its row.
-                //   s0 rows: [v0, v3, v5, v8]   s1 rows: [v1, v4, v6, -]   s2 rows: [v2, -, v7, -]
-                const float r0 = fold32(v0, v5), r1 = fold32(v1, v6), r2 = fold32(v2, v7), r3 = fold32(v3, v8),
-                            r4 = fold32(v4, 0.0f);
-                float s0 = fold16(r0, r3), s1 = fold16(r1, r4), s2 = fold16(r2, 0.0f);
-                s0 = row_sum_lane15(s0);
-                s1 = row_sum_lane15(s1);
-                s2 = row_sum_lane15(s2);
-                if ((lane & 15) == 15) {
-                    float* row = &s_acc[j][0];
-                    atomicAdd(row + slot0, s0);
-                    if (slot1 >= 0) atomicAdd(row + slot1, s1);
-                    if (slot2 >= 0) atomicAdd(row + slot2, s2);
-                }
-            }
+            // Every lane evaluates the body.  A dead lane (pixel that does not blend this splat) runs it with
+            // alpha = 0, which leaves its state untouched without a single select: T / (1 - 0) = T, the
+            // colour behind it becomes 0 * colour + 1 * rec = rec, and every partial below is an exact zero
+            // (G and dL/dalpha are forced to 0 as well).
+            const float alpha_l = live ? alpha : 0.0f;
+            const float om = 1.f - alpha_l;
+            const float inv = __builtin_amdgcn_rcpf(om);  // v_rcp_f32, 1 ulp; exactly 1 for a dead lane
+            const float Tn = T * inv;
+            const float w = alpha_l * Tn;
+            const v2f col_rg = {col.x, col.y};
+            // `rec` is the colour accumulated behind this splat (the reference's accum_rec after its update,
+            // backward.cu:503-513)
+            const v2f d_rg = (col_rg - rec_rg) * dp_rg;
+            float dL_dalpha = d_rg.x + d_rg.y;
+            dL_dalpha += (col.z - rec_b) * dpb;
+            dL_dalpha *= Tn;
+            dL_dalpha += (-T_final * inv) * bgdot;
+            dL_dalpha = live ? dL_dalpha : 0.0f;
+            const float Gl = live ? G : 0.0f;
+            const float dL_dG = q.w * dL_dalpha;
+            const v2f gd = Gl * d;  // {G dx, G dy}
+            const v2f gx = {gd.x, gd.x}, gy = {gd.y, gd.y};
+            // {dG/ddelx, dG/ddely} = -gdx * {a, b} - gdy * {b, c}
+            const v2f dG = -gx * (v2f){q.x, q.y} - gy * (v2f){q.y, q.z};
+            const v2f v01 = (dL_dG * dG) * ddel;            // ACC_DX, ACC_DY
+            const v2f h = -0.5f * gd;
+            const v2f v23 = ((v2f){h.x, h.x} * d) * dL_dG;  // ACC_CON_A, ACC_CON_B
+            const float v4 = h.y * dy * dL_dG;              // ACC_CON_C
+            const float v5 = Gl * dL_dalpha;                // ACC_OPAC
+            const v2f v67 = w * dp_rg;                      // ACC_R, ACC_G
+            const float v8 = w * dpb;                       // ACC_B
+            // state for the next (nearer) splat: transmittance in front of this one, and the colour behind
+            // the next one = this splat blended over what was behind it (same expression the reference
+            // evaluates one step later from its last_alpha / last_color)
+            T = Tn;
+            rec_rg = alpha_l * col_rg + om * rec_rg;
+            rec_b = alpha_l * col.z + om * rec_b;
+
+            // Sum over the quadrant's 16 pixels: four exchange steps, each halving the number of registers.
+            const float a01 = row_fold<DPP_ROW_MIRROR>(v01.x, v01.y, up8);
+            const float a23 = row_fold<DPP_ROW_MIRROR>(v23.x, v23.y, up8);
+            const float a45 = row_fold<DPP_ROW_MIRROR>(v4, v5, up8);
+            const float a67 = row_fold<DPP_ROW_MIRROR>(v67.x, v67.y, up8);
+            const float a8 = row_pair_sum<DPP_ROW_MIRROR>(v8);
+            const float b03 = row_fold<DPP_ROW_HALF_MIRROR>(a01, a23, up4);
+            const float b47 = row_fold<DPP_ROW_HALF_MIRROR>(a45, a67, up4);
+            const float b8 = row_pair_sum<DPP_ROW_HALF_MIRROR>(a8);
+            const float c07 = row_fold<DPP_QUAD_XOR2>(b03, b47, up2);
+            const float c8 = row_pair_sum<DPP_QUAD_XOR2>(b8);
+            const float total = row_fold<DPP_QUAD_XOR1>(c07, c8, up1);
+            if (have && my_slot >= 0 && total != 0.0f) atomicAdd(&s_acc[j][my_slot], total);
         }
         __syncthreads();
         // Flush: 16 lanes per splat, lane c adds slot c of the splat's 64-byte accumulator row.

@@ -34,14 +34,21 @@ __device__ __forceinline__ bool splat_reaches(float sx, float sy, float a, float
     return 0.5f * qmin <= tau + 0.01f + 1e-5f * mag;
 }
 
-// Pixel layout of a tile's 256 threads: each wave64 covers one 8x8 pixel block (2x2 blocks per 16x16 tile), lanes
-// row-major inside the block.  A square block is touched by fewer splats than a 16x4 strip of the same area, and a
-// touching splat covers more of its pixels.  final_T / n_contrib are stored per tile in thread order, so the
-// forward and backward kernels (and the state decoder) share this mapping.
+// Pixel layout of a tile's 256 threads: each wave64 covers one 8x8 pixel block (2x2 blocks per 16x16 tile), and
+// inside a block every 16-lane row of the wave (the unit the DPP row operations work on) covers one 4x4 quadrant,
+// row-major inside the quadrant.  final_T / n_contrib are stored per tile in thread order, so the forward and
+// backward kernels (and the state decoder) share this mapping.
 #define NGS_WAVE_W 8
 #define NGS_WAVE_H 8
-__device__ __forceinline__ int tile_local_x(int tid) { return ((tid >> 6) & 1) * NGS_WAVE_W + (tid & 7); }
-__device__ __forceinline__ int tile_local_y(int tid) { return (tid >> 7) * NGS_WAVE_H + ((tid >> 3) & 7); }
+#define NGS_QUAD 4
+__device__ __forceinline__ int tile_local_x(int tid)
+{
+    return ((tid >> 6) & 1) * NGS_WAVE_W + ((tid >> 4) & 1) * NGS_QUAD + (tid & 3);
+}
+__device__ __forceinline__ int tile_local_y(int tid)
+{
+    return (tid >> 7) * NGS_WAVE_H + ((tid >> 5) & 1) * NGS_QUAD + ((tid >> 2) & 3);
+}
 
 // exp(x) for the compositing kernels, whose argument is the Gaussian exponent: never positive when it is used.
 // Same operation sequence as the device library's expf (argument reduction by log2(e) in two parts, v_exp_f32,

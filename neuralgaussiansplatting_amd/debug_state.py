@@ -31,9 +31,11 @@ def decode_state(_C, P, R, W, H, geom, binning, img):
         point_list=_view(binning, bl["point_list"], np.uint32, R),
         ranges=_view(img, il["ranges"], np.uint32, 2 * T).reshape(T, 2),
     )
-    # per tile in thread order: [block row][block column][row in block][column in block], 8x8 blocks (one per wave)
-    ft = _view(img, il["final_T"], np.float32, T * 256).reshape(gy, gx, 2, 2, 8, 8)
-    nc = _view(img, il["n_contrib"], np.uint32, T * 256).reshape(gy, gx, 2, 2, 8, 8)
-    out["final_T"] = ft.transpose(0, 2, 4, 1, 3, 5).reshape(gy * 16, gx * 16)[:H, :W]
-    out["n_contrib"] = nc.transpose(0, 2, 4, 1, 3, 5).reshape(gy * 16, gx * 16)[:H, :W]
+    # per tile in thread order: 2x2 blocks of 8x8 pixels (one per wave), each 2x2 quadrants of 4x4 pixels (one per
+    # 16-lane row of the wave), row-major inside a quadrant
+    ft = _view(img, il["final_T"], np.float32, T * 256).reshape(gy, gx, 2, 2, 2, 2, 4, 4)
+    nc = _view(img, il["n_contrib"], np.uint32, T * 256).reshape(gy, gx, 2, 2, 2, 2, 4, 4)
+    order = (0, 2, 4, 6, 1, 3, 5, 7)  # -> [tile row][block row][quadrant row][y][tile column][block column][quadrant column][x]
+    out["final_T"] = ft.transpose(order).reshape(gy * 16, gx * 16)[:H, :W]
+    out["n_contrib"] = nc.transpose(order).reshape(gy * 16, gx * 16)[:H, :W]
     return out
