@@ -139,11 +139,11 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
                 const uint32_t pos = (uint32_t)(first - mine);
                 const float4 p = s_rec[mine][0];
                 const float4 q = s_rec[mine][1];
-                r0 = pos < qmax0 && splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, bx0, bx0 + 3.0f, by0, by0 + 3.0f);
-                r1 = pos < qmax1 && splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, bx0 + 4.0f, bx0 + 7.0f, by0, by0 + 3.0f);
-                r2 = pos < qmax2 && splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, bx0, bx0 + 3.0f, by0 + 4.0f, by0 + 7.0f);
-                r3 = pos < qmax3 &&
-                     splat_reaches(p.x, p.y, q.x, q.y, q.z, p.z, bx0 + 4.0f, bx0 + 7.0f, by0 + 4.0f, by0 + 7.0f);
+                const unsigned bits = splat_reaches_quadrants(p.x, p.y, q.x, q.y, q.z, p.z, bx0, by0);
+                r0 = pos < qmax0 && (bits & 1u);
+                r1 = pos < qmax1 && (bits & 2u);
+                r2 = pos < qmax2 && (bits & 4u);
+                r3 = pos < qmax3 && (bits & 8u);
             }
             const unsigned long long m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
             const unsigned long long below = (1ull << lane) - 1ull;

@@ -20,18 +20,60 @@ __device__ __forceinline__ bool splat_reaches(float sx, float sy, float a, float
     const float xl = x0 - sx, xh = x1 - sx, yl = y0 - sy, yh = y1 - sy;
     const bool inside = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
     const float tb = 2.0f * b;
+    // reciprocals instead of divisions: an ulp of error in the minimiser's position moves the minimum by a
+    // second-order amount, far inside the margin below
+    const float mbc = -b * __builtin_amdgcn_rcpf(c), mba = -b * __builtin_amdgcn_rcpf(a);
     // edges x = xl, x = xh: q is minimised over y at -b x / c, clamped to the edge
-    const float ya = fminf(fmaxf(-b * xl / c, yl), yh), yb = fminf(fmaxf(-b * xh / c, yl), yh);
+    const float ya = fminf(fmaxf(mbc * xl, yl), yh), yb = fminf(fmaxf(mbc * xh, yl), yh);
     const float q0 = a * xl * xl + tb * xl * ya + c * ya * ya;
     const float q1 = a * xh * xh + tb * xh * yb + c * yb * yb;
     // edges y = yl, y = yh
-    const float xa = fminf(fmaxf(-b * yl / a, xl), xh), xb = fminf(fmaxf(-b * yh / a, xl), xh);
+    const float xa = fminf(fmaxf(mba * yl, xl), xh), xb = fminf(fmaxf(mba * yh, xl), xh);
     const float q2 = a * xa * xa + tb * xa * yl + c * yl * yl;
     const float q3 = a * xb * xb + tb * xb * yh + c * yh * yh;
     const float qmin = inside ? 0.0f : fminf(fminf(q0, q1), fminf(q2, q3));
     const float mx = fmaxf(fabsf(xl), fabsf(xh)), my = fmaxf(fabsf(yl), fabsf(yh));
     const float mag = a * mx * mx + fabsf(tb) * mx * my + c * my * my;
     return 0.5f * qmin <= tau + 0.01f + 1e-5f * mag;
+}
+
+// The same test for the four 4x4 quadrants of an 8x8 block at once (corner pixel (bx0, by0)); bit k of the result
+// is quadrant (k & 1, k >> 1).  The quadrants share their edge lines, so the sixteen clamped parabola minima are
+// formed from four x offsets and four y offsets; the unclamped minimisers use reciprocals instead of divisions (an
+// error of an ulp in the minimiser's position moves the minimum by a second-order amount), and the margin uses the
+// block's extents, which are at least the quadrant's.
+__device__ __forceinline__ unsigned splat_reaches_quadrants(float sx, float sy, float a, float b, float c, float tau,
+                                                            float bx0, float by0)
+{
+    if (!(a > 0.0f && c > 0.0f && a * c - b * b > 0.0f)) return 0xfu;
+    const float ex[4] = {bx0 - sx, (bx0 + 3.0f) - sx, (bx0 + 4.0f) - sx, (bx0 + 7.0f) - sx};
+    const float ey[4] = {by0 - sy, (by0 + 3.0f) - sy, (by0 + 4.0f) - sy, (by0 + 7.0f) - sy};
+    const float tb = 2.0f * b;
+    const float mbc = -b * __builtin_amdgcn_rcpf(c), mba = -b * __builtin_amdgcn_rcpf(a);
+    float qv[4][2], qh[4][2];  // [edge][range of the other coordinate]
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float x = ex[i], ax2 = a * x * x, tbx = tb * x, y0 = mbc * x;
+        const float y = ey[i], cy2 = c * y * y, tby = tb * y, x0 = mba * y;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const float ys = fminf(fmaxf(y0, ey[2 * k]), ey[2 * k + 1]);
+            qv[i][k] = ax2 + tbx * ys + c * ys * ys;
+            const float xs = fminf(fmaxf(x0, ex[2 * k]), ex[2 * k + 1]);
+            qh[i][k] = cy2 + tby * xs + a * xs * xs;
+        }
+    }
+    const float mx = fmaxf(fabsf(ex[0]), fabsf(ex[3])), my = fmaxf(fabsf(ey[0]), fabsf(ey[3]));
+    const float bound = 2.0f * (tau + 0.01f + 1e-5f * (a * mx * mx + fabsf(tb) * mx * my + c * my * my));
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int kx = k & 1, ky = k >> 1;
+        const bool inside = ex[2 * kx] <= 0.0f && ex[2 * kx + 1] >= 0.0f && ey[2 * ky] <= 0.0f && ey[2 * ky + 1] >= 0.0f;
+        const float qmin = fminf(fminf(qv[2 * kx][ky], qv[2 * kx + 1][ky]), fminf(qh[2 * ky][kx], qh[2 * ky + 1][kx]));
+        if (inside || qmin <= bound) bits |= 1u << k;
+    }
+    return bits;
 }
 
 // Pixel layout of a tile's 256 threads: each wave64 covers one 8x8 pixel block (2x2 blocks per 16x16 tile), and
