@@ -296,9 +296,17 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get(args.config, {}).get(dom)
+            # the compositing kernels are limited by vector-ALU issue, not by HBM: quote the counter-derived issue
+            # fraction (share of the one-wave64-FP32-instruction-per-2-cycles peak) of the last profiled build too
+            valu = None
+            vpath = os.path.join(ROOT, "profiles", "valu_issue.json")
+            if os.path.exists(vpath):
+                with open(vpath) as f:
+                    valu = json.load(f).get(args.config, {}).get(dom)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes": int(nbytes[dom])}
+                        "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes": int(nbytes[dom]),
+                        "valu_issue_frac": valu}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene_cpu, synthetic.make_view(W, H, index=0, count=8), W, H, D, tanx, tany, dL)

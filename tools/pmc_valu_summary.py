@@ -2,7 +2,10 @@
 """Vector-ALU load of each kernel from one rocprofv3 --pmc pass over
 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE.
 
-    python tools/pmc_valu_summary.py gpurun_out/f_pmc_valu > profiles/r01_c4_valu.md
+    python tools/pmc_valu_summary.py gpurun_out/f_pmc_valu [profiles/valu_issue.json c4] > profiles/r01_c4_valu.md
+
+With the two optional arguments the issue fractions are also stored in that JSON file under the given configuration
+name (bench.py quotes the dominant kernel's figure next to its HBM roofline).
 
 Units on gfx950: SQ_INSTS_* count wave-instructions; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles
 summed over waves; GRBM_GUI_ACTIVE is the sum of the 8 XCDs' busy cycles.  A SIMD issues at most one wave64 FP32
@@ -14,6 +17,7 @@ one slot (tools/probes/valu_rate_probe.hip), so a kernel built from them saturat
 import collections
 import csv
 import glob
+import json
 import os
 import sys
 
@@ -33,6 +37,7 @@ def main():
     print("| kernel | launches | VALU wave-instr / launch | SALU | LDS | cycles (per XCD) | VALU issue fraction | "
           "waves resident per SIMD | wave time waiting on memory/LDS counters | wave time stalled at issue |")
     print("|---|---|---|---|---|---|---|---|---|---|")
+    fractions = {}
     for k in sorted(tot, key=lambda k: -tot[k].get("GRBM_GUI_ACTIVE", 0)):
         c, n = tot[k], len(launches[k])
         cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8 / n
@@ -40,11 +45,20 @@ def main():
             continue
         valu = c["SQ_INSTS_VALU"] / n
         wave_q = c.get("SQ_WAVE_CYCLES", 0) / n
+        fractions[k.split("<")[0].replace("_kernel", "")] = round(valu * 2 / (SIMDS * cyc), 4)
         print("| `%s` | %d | %.3g | %.3g | %.3g | %.3g | %.2f | %.1f | %.0f %% | %.0f %% |" % (
             k, n, valu, c.get("SQ_INSTS_SALU", 0) / n, c.get("SQ_INSTS_LDS", 0) / n, cyc,
             valu * 2 / (SIMDS * cyc), wave_q * 4 / (SIMDS * cyc),
             100 * c.get("SQ_WAIT_ANY", 0) / n / wave_q if wave_q else 0,
             100 * c.get("SQ_WAIT_INST_ANY", 0) / n / wave_q if wave_q else 0))
+    if len(sys.argv) > 3:
+        table = {}
+        if os.path.exists(sys.argv[2]):
+            with open(sys.argv[2]) as f:
+                table = json.load(f)
+        table[sys.argv[3]] = fractions
+        with open(sys.argv[2], "w") as f:
+            json.dump(table, f, indent=1)
 
 
 if __name__ == "__main__":
