@@ -73,12 +73,22 @@ __global__ __launch_bounds__(256) void knn_bounds_kernel(int P, const float* __r
         lo[a] = wave_min_f(lo[a]);
         hi[a] = wave_max_f(hi[a]);
     }
+    // one set of atomics per workgroup: thousands of waves hitting the same six words would serialise
+    __shared__ float s_lo[4][3], s_hi[4][3];
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            if (lo[a] != FLT_MAX) atomicMin(&bounds[a], knn_encode(lo[a]));
-            if (hi[a] != -FLT_MAX) atomicMax(&bounds[3 + a], knn_encode(hi[a]));
+            s_lo[threadIdx.x >> 6][a] = lo[a];
+            s_hi[threadIdx.x >> 6][a] = hi[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float l = fminf(fminf(s_lo[0][a], s_lo[1][a]), fminf(s_lo[2][a], s_lo[3][a]));
+        const float h = fmaxf(fmaxf(s_hi[0][a], s_hi[1][a]), fmaxf(s_hi[2][a], s_hi[3][a]));
+        if (l != FLT_MAX) atomicMin(&bounds[a], knn_encode(l));
+        if (h != -FLT_MAX) atomicMax(&bounds[3 + a], knn_encode(h));
     }
 }
 
@@ -215,28 +225,44 @@ __global__ __launch_bounds__(256) void knn_search_kernel(int P, int L, int S, co
     const KnnBox qbox = leaves[own];
     float reach = wave_max_f(valid ? b2 : 0.0f);
 
-    for (int s0 = 0; s0 < S; s0 += 64) {
-        bool pass = false;
-        if (s0 + lane < S) pass = knn_box_box(supers[s0 + lane], qbox) <= reach;
-        uint64_t smask = __ballot(pass);
-        while (smask) {
-            const int sb = s0 + __builtin_ctzll(smask);
-            smask &= smask - 1;
-            const int lf = sb * 64 + lane;
-            bool pass2 = false;
-            if (lf < L && lf != own) pass2 = knn_box_box(leaves[lf], qbox) <= reach;
-            uint64_t lmask = __ballot(pass2);
-            while (lmask) {
-                const int l = sb * 64 + __builtin_ctzll(lmask);
-                lmask &= lmask - 1;
-                const KnnBox box = leaves[l];
-                const bool need = valid && !(knn_box_point(box, q) > b2);  // simple_knn.cu:172
-                if (__ballot(need) == 0) continue;
-                const int n = min(KNN_LEAF, P - l * KNN_LEAF);
-                float4 pt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (lane < n) pt = sorted[(size_t)l * KNN_LEAF + lane];
-                knn_scan_leaf(pt, n, q, -1, b0, b1, b2);
-                reach = wave_max_f(valid ? b2 : 0.0f);
+    // One candidate leaf: taken only if some lane still needs it (the per-point test of simple_knn.cu:172).
+    auto visit = [&](const int l) {
+        const KnnBox box = leaves[l];
+        const bool need = valid && !(knn_box_point(box, q) > b2);
+        if (__ballot(need) == 0) return;
+        const int n = min(KNN_LEAF, P - l * KNN_LEAF);
+        float4 pt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (lane < n) pt = sorted[(size_t)l * KNN_LEAF + lane];
+        knn_scan_leaf(pt, n, q, -1, b0, b1, b2);
+        reach = wave_max_f(valid ? b2 : 0.0f);
+    };
+    // Near things first, so that the rejection radius is small before the sweep over everything else: the leaves
+    // next to this one in Morton order, then the super boxes outwards from the one that holds this leaf.
+    constexpr int NEAR = 2;
+    for (int d = 1; d <= NEAR; d++) {
+        if (own - d >= 0) visit(own - d);
+        if (own + d < L) visit(own + d);
+    }
+    const int chunks = (S + 63) / 64, home = (own / 64) / 64;
+    for (int k = 0; k < chunks; k++) {
+        for (int side = 0; side < 2; side++) {
+            const int c = side ? home - k : home + k;
+            if ((side && k == 0) || c < 0 || c >= chunks) continue;  // wave-uniform
+            const int s0 = c * 64;
+            bool pass = false;
+            if (s0 + lane < S) pass = knn_box_box(supers[s0 + lane], qbox) <= reach;
+            uint64_t smask = __ballot(pass);
+            while (smask) {
+                const int sb = s0 + __builtin_ctzll(smask);
+                smask &= smask - 1;
+                const int lf = sb * 64 + lane;
+                bool pass2 = false;
+                if (lf < L && abs(lf - own) > NEAR) pass2 = knn_box_box(leaves[lf], qbox) <= reach;
+                uint64_t lmask = __ballot(pass2);
+                while (lmask) {
+                    visit(sb * 64 + __builtin_ctzll(lmask));
+                    lmask &= lmask - 1;
+                }
             }
         }
     }
@@ -284,7 +310,7 @@ void ngs_launch_knn(hipStream_t s, int P, const float* points, char* workspace, 
     const int in_buf = ngs_sort_input_buffer(end_bit);
 
     (void)hipMemsetD32Async((hipDeviceptr_t)bounds, (int)0x80000000u, 6, s);  // encode(0.0f)
-    hipLaunchKernelGGL(knn_bounds_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, P, points, bounds);
+    hipLaunchKernelGGL(knn_bounds_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, s, P, points, bounds);
     hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, P, points, bounds, keys[in_buf], vals[in_buf]);
     ngs_launch_sort_tile_bits(s, P, keys, vals, hist, totals, end_bit);  // stable: equal codes keep index order
     hipLaunchKernelGGL(knn_gather_kernel, dim3(nb), dim3(256), 0, s, P, points, vals[0], sorted, leaves);
