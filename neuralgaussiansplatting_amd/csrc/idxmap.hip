@@ -179,15 +179,30 @@ __global__ __launch_bounds__(256) void idxmap_backward_gather_kernel(int P, int 
     if (g >= (size_t)P) return;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const IdxSquare q = idx_square(means[3 * g], means[3 * g + 1], means[3 * g + 2], view, proj, W, H);
-    if (q.visible && c >= IDX_FIRST_COPIED / 4) {
-        for (int y = q.y0; y < q.y1; y++)
-            for (int x = q.x0; x < q.x1; x++) {
-                const size_t pix = (size_t)y * W + x;
-                if (out_idx[pix] == (int)g) {
+    if (q.visible) {
+        // The 16 lanes of a Gaussian look at 16 pixels of its square at a time (one round trip to the index map
+        // instead of one per pixel), then add the rows of the pixels that matched, in pixel order.
+        const int w = q.x1 - q.x0, npx = w * (q.y1 - q.y0);
+        const int shift = (int)(threadIdx.x & 48);  // position of this Gaussian's 16 lanes in the wave's ballot
+        for (int base = 0; base < npx; base += 16) {
+            const int k = base + c;
+            bool match = false;
+            if (k < npx) {
+                const int dy = k / w;
+                match = out_idx[(size_t)(q.y0 + dy) * W + (q.x0 + (k - dy * w))] == (int)g;
+            }
+            unsigned hits = (unsigned)(__ballot(match) >> shift) & 0xffffu;
+            while (hits) {
+                const int kk = base + __builtin_ctz(hits);
+                hits &= hits - 1u;
+                const int dy = kk / w;
+                const size_t pix = (size_t)(q.y0 + dy) * W + (q.x0 + (kk - dy * w));
+                if (c >= IDX_FIRST_COPIED / 4) {
                     const float4 v = *(const float4*)(dL_dfeature + pix * IDX_FEATURES + 4 * c);
                     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
             }
+        }
         if (4 * c < IDX_FIRST_COPIED) acc.x = 0.0f;  // element 24 belongs to the positional encoding
     }
     stream_store4(dL_dfeature_vector + g * IDX_FEATURES + 4 * c, acc);
