@@ -44,10 +44,11 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
     return {
         "preprocess_fwd": P * (12 + 8) + vP * (32 + 12 * c + 49),
         "scan_block_sums": 8 * ((P + 255) // 256),
-        "duplicate_with_keys": 4 * P + 12 * vP + 12 * R,
-        "radix_sort_tile_bits": tile_passes * 24 * R,
-        "tile_ranges": 8 * R + 16 * T,
-        "segment_sort_depth": 24 * R + 8 * T,
+        # the tile-level sort moves (tile id, Gaussian index) pairs of 8 bytes; the depth joins in the per-tile sort
+        "duplicate_with_keys": 4 * P + 8 * vP + 8 * R,
+        "radix_sort_tile_bits": tile_passes * 16 * R,
+        "tile_ranges": 4 * R + 16 * T,
+        "segment_sort_depth": 4 * R + 4 * R + 12 * R + 8 * T,
         "render_fwd": 40 * R + 8 * T + 20 * W * H,
         "zero_accumulator": 64 * P,
         "render_bwd": 112 * R + 8 * T + 20 * W * H,

@@ -72,25 +72,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
 // each lane locating its Gaussian by binary search over the wave's prefix sums,
 // so key/value stores are fully coalesced whatever the footprint sizes are.
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const uint2* __restrict__ rect,
-                                                                    const float* __restrict__ depth,
                                                                     const uint32_t* __restrict__ tiles,
                                                                     const uint32_t* __restrict__ block_offs,
-                                                                    int grid_x, uint64_t* __restrict__ keys,
+                                                                    int grid_x, uint32_t* __restrict__ keys,
                                                                     uint32_t* __restrict__ vals)
 {
     __shared__ uint32_t s_incl[NGS_GAUSS_BLOCK];  // per wave: inclusive prefix of tiles within the wave
     __shared__ uint2 s_rect[NGS_GAUSS_BLOCK];
-    __shared__ uint32_t s_depth[NGS_GAUSS_BLOCK];
     __shared__ uint32_t s_wave_tot[NGS_GAUSS_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + tid;
     uint32_t cnt = 0;
     if (idx < P) {
         cnt = tiles[idx];
-        if (cnt) {
-            s_rect[tid] = rect[idx];
-            s_depth[tid] = __float_as_uint(depth[idx]);
-        }
+        if (cnt) s_rect[tid] = rect[idx];
     }
     const uint32_t incl = wave_incl_scan_u32(cnt, lane);
     s_incl[tid] = incl;
@@ -113,23 +108,22 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
         const uint32_t x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu;
         const uint32_t w = x1 - x0;
         const uint32_t ty = y0 + local / w, tx = x0 + local % w;
-        const uint64_t key = ((uint64_t)(ty * (uint32_t)grid_x + tx) << 32) | s_depth[wave * 64 + j];
-        keys[(size_t)wave_base + k] = key;
+        keys[(size_t)wave_base + k] = ty * (uint32_t)grid_x + tx;  // the depth half of the key joins in the per-tile sort
         vals[(size_t)wave_base + k] = (uint32_t)(blockIdx.x * NGS_GAUSS_BLOCK + wave * 64 + j);
     }
 }
 
 // rasterizer_impl.cu:116-138; `ranges` was zeroed by the caller.
-__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t L, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t L, const uint32_t* __restrict__ keys,
                                                           uint2* __restrict__ ranges)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
-    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    const uint32_t cur = keys[idx];
     if (idx == 0) {
         ranges[cur].x = 0;
     } else {
-        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        const uint32_t prev = keys[idx - 1];
         if (cur != prev) {
             ranges[prev].y = (uint32_t)idx;
             ranges[cur].x = (uint32_t)idx;
@@ -145,15 +139,15 @@ void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* bloc
                        misc, mailbox);
 }
 
-void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const float* depth, const uint32_t* tiles,
-                          const uint32_t* block_offs, int grid_x, uint64_t* keys, uint32_t* vals)
+void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
+                          int grid_x, uint32_t* keys, uint32_t* vals)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
-    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, rect, depth, tiles, block_offs,
-                       grid_x, keys, vals);
+    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, rect, tiles, block_offs, grid_x,
+                       keys, vals);
 }
 
-void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint64_t* keys, int T, uint2* ranges)
+void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint32_t* keys, int T, uint2* ranges)
 {
     (void)hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s);
     if (R > 0)

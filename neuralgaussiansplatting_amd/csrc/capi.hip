@@ -306,32 +306,34 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     char* bb = binning_alloc(binning_ctx, bl.total);
     if (!bb) return fail("ngs_rasterize_forward", "binning allocator returned NULL");
     bb = ngs_align_ptr(bb);
-    uint64_t* keys[2] = {(uint64_t*)(bb + bl.keys[0]), (uint64_t*)(bb + bl.keys[1])};
+    uint64_t* const keys64 = (uint64_t*)(bb + bl.keys[0]);       // sorted (tile << 32 | depth) keys, written last
+    uint64_t* const spare64 = (uint64_t*)(bb + bl.keys[1]);      // tile-id ping/pong, then spare of the long sort
+    uint32_t* tkeys[2] = {(uint32_t*)spare64, (uint32_t*)spare64 + R};
     uint32_t* vals[2] = {(uint32_t*)(bb + bl.vals[0]), (uint32_t*)(bb + bl.vals[1])};
     uint32_t* hist = (uint32_t*)(bb + bl.hist);
     uint32_t* totals = (uint32_t*)(bb + bl.totals);
 
     const int T = cam.grid_x * cam.grid_y;
-    const int end_bit = 32 + (int)higher_msb((uint32_t)T);
-    const int in_buf = ngs_sort_input_buffer(end_bit);
+    const int tile_bits = (int)higher_msb((uint32_t)T);
+    const int in_buf = ngs_sort_input_buffer(tile_bits);
     if (R > 0) {
         prof_begin(ps, ST_DUPLICATE, st);
-        ngs_launch_duplicate(st, P, rect, depth, tiles, block_offs, cam.grid_x, keys[in_buf], vals[in_buf]);
+        ngs_launch_duplicate(st, P, rect, tiles, block_offs, cam.grid_x, tkeys[in_buf], vals[in_buf]);
         prof_end(ps, ST_DUPLICATE, st);
         NGS_STAGE("duplicateWithKeys");
         prof_begin(ps, ST_SORT, st);
-        ngs_launch_sort_tile_bits(st, R, keys, vals, hist, totals, end_bit);
+        ngs_launch_sort_tile_bits(st, R, tkeys, vals, hist, totals, tile_bits);
         prof_end(ps, ST_SORT, st);
         NGS_STAGE("sort");
     }
     uint2* ranges = (uint2*)(ib + il.ranges);
     prof_begin(ps, ST_RANGES, st);
-    ngs_launch_tile_ranges(st, R, keys[0], T, ranges);
+    ngs_launch_tile_ranges(st, R, tkeys[0], T, ranges);
     prof_end(ps, ST_RANGES, st);
     NGS_STAGE("identifyTileRanges");
     if (R > 0) {
         prof_begin(ps, ST_SEGSORT, st);
-        ngs_launch_sort_segments(st, T, ranges, keys, vals);
+        ngs_launch_sort_segments(st, T, ranges, depth, keys64, spare64, vals);
         prof_end(ps, ST_SEGSORT, st);
         NGS_STAGE("sort (depth)");
     }

@@ -101,10 +101,10 @@ __device__ __forceinline__ uint32_t knn_spread_bits(uint32_t x)  // simple_knn.c
     return x;
 }
 
-// key = Morton code in the bits the global radix passes sort (32..61), value = point index (simple_knn.cu:54-70).
+// key = 30-bit Morton code, value = point index (simple_knn.cu:54-70).
 __global__ __launch_bounds__(256) void knn_morton_kernel(int P, const float* __restrict__ points,
                                                          const uint32_t* __restrict__ bounds,
-                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void knn_morton_kernel(int P, const float* __r
         const float t = ((points[(size_t)3 * i + a] - lo) / (hi - lo)) * 1023.0f;
         code |= knn_spread_bits((uint32_t)t) << a;  // the conversion saturates and maps NaN to 0, as on the reference's GPU
     }
-    keys[i] = (uint64_t)code << 32;
+    keys[i] = code;
     vals[i] = (uint32_t)i;
 }
 
@@ -297,7 +297,7 @@ void ngs_launch_knn(hipStream_t s, int P, const float* points, char* workspace, 
     const KnnLayout k = knn_layout((size_t)P);
     char* const base = ngs_align_ptr(workspace);
     char* const bb = base + k.bin_off;
-    uint64_t* const keys[2] = {(uint64_t*)(bb + k.bin.keys[0]), (uint64_t*)(bb + k.bin.keys[1])};
+    uint32_t* const keys[2] = {(uint32_t*)(bb + k.bin.keys[0]), (uint32_t*)(bb + k.bin.keys[1])};
     uint32_t* const vals[2] = {(uint32_t*)(bb + k.bin.vals[0]), (uint32_t*)(bb + k.bin.vals[1])};
     uint32_t* const hist = (uint32_t*)(bb + k.bin.hist);
     uint32_t* const totals = (uint32_t*)(bb + k.bin.totals);
@@ -306,7 +306,7 @@ void ngs_launch_knn(hipStream_t s, int P, const float* points, char* workspace, 
     KnnBox* const supers = (KnnBox*)(base + k.supers);
     uint32_t* const bounds = (uint32_t*)(base + k.bounds);
     const int nb = (P + 255) / 256, L = (P + KNN_LEAF - 1) / KNN_LEAF, S = (L + 63) / 64;
-    const int end_bit = 62;  // 30 Morton bits above bit 32
+    const int end_bit = 30;  // Morton bits
     const int in_buf = ngs_sort_input_buffer(end_bit);
 
     (void)hipMemsetD32Async((hipDeviceptr_t)bounds, (int)0x80000000u, 6, s);  // encode(0.0f)

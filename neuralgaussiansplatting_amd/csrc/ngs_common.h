@@ -49,7 +49,8 @@ struct ImageLayout {
 };
 
 struct BinLayout {
-    size_t keys[2];  // u64[R] ping/pong; keys[0] holds the sorted keys when the sort is done
+    size_t keys[2];  // u64[R] each; keys[0] receives the sorted 64-bit keys, keys[1] holds the two u32[R] tile-id
+                     // arrays of the tile-level sort (then serves as the spare buffer of the long-segment sort)
     size_t vals[2];  // u32[R] ping/pong; vals[0] is the sorted point list
     size_t hist;     // u32[256 * sort_blocks] digit-major per-block histogram
     size_t totals;   // u32[256] per-digit totals
@@ -173,17 +174,18 @@ void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const flo
 // or NULL.
 void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* block_sums, uint32_t* block_offs,
                                 uint32_t* misc, unsigned long long* mailbox);
-void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const float* depth, const uint32_t* tiles,
-                          const uint32_t* block_offs, int grid_x, uint64_t* keys, uint32_t* vals);
-void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint64_t* keys, int T, uint2* ranges);
-// radix_sort.hip: stable sort on key bits [0,end_bit) in two levels: global radix passes over the tile bits
-// (32..end_bit), result in keys[0]/vals[0], then, once the tile ranges are known, a per-tile sort on the 32 depth
-// bits.  ngs_sort_input_buffer returns the buffer index (0 or 1) the unsorted input must be written to.
-int ngs_sort_input_buffer(int end_bit);
-void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint64_t* const keys[2], uint32_t* const vals[2],
-                               uint32_t* hist, uint32_t* totals, int end_bit);
-void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, uint64_t* const keys[2],
-                              uint32_t* const vals[2]);
+void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
+                          int grid_x, uint32_t* tile_keys, uint32_t* vals);
+void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint32_t* tile_keys, int T, uint2* ranges);
+// radix_sort.hip: stable sort of the instances on (tile, depth) in two levels: global radix passes over the low
+// `bits` bits of 32-bit keys (tile ids) carried with 32-bit values, result in keys[0]/vals[0]; then, once the tile
+// ranges are known, a per-tile sort on the depth of the listed Gaussians, which also writes the 64-bit keys.
+// ngs_sort_input_buffer returns the buffer index (0 or 1) the unsorted input must be written to.
+int ngs_sort_input_buffer(int bits);
+void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint32_t* const keys[2], uint32_t* const vals[2],
+                               uint32_t* hist, uint32_t* totals, int bits);
+void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint64_t* keys,
+                              uint64_t* spare_keys, uint32_t* const vals[2]);
 // render_fwd.hip
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,

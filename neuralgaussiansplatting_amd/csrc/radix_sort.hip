@@ -1,27 +1,32 @@
-// Stable sort of (uint64 key, uint32 value) pairs on key bits [0,end_bit),
-// key = (tile << 32) | depth bits, written for wave64 without any library.
+// Sort of the (tile, depth) instance list, written for wave64 without any library.
 // It produces the result the reference obtains from
-// cub::DeviceRadixSort::SortPairs (cuda_rasterizer/rasterizer_impl.cu:303-308):
-// keys ascending on the masked bits, ties in input order.
+// cub::DeviceRadixSort::SortPairs over 64-bit keys (tile << 32) | depth bits
+// (cuda_rasterizer/rasterizer_impl.cu:303-308): keys ascending, ties in input
+// order.
 //
 // Two levels, exploiting the key's structure instead of running
-// ceil(end_bit/8) global passes:
+// ceil(end_bit/8) global passes over 12-byte pairs:
 //
-//  1. Global LSD radix passes over the TILE bits only (bits 32..end_bit, one
-//     or two 8-bit passes).  Per pass: per-workgroup digit histogram (stored
+//  1. Global stable LSD radix passes over the TILE id only (one or two 8-bit
+//     passes), on 8-byte (tile id, Gaussian index) pairs: the depth does not
+//     travel with them.  Per pass: per-workgroup digit histogram (stored
 //     digit-major), one workgroup per digit turning its histogram row into
 //     exclusive prefixes, and a scatter that ranks pairs inside the workgroup
 //     in input order with wave ballots, reorders them through LDS so each
 //     digit's run leaves as contiguous stores, and writes them at
 //     digit base + workgroup prefix + rank.  Afterwards every tile's pairs are
 //     contiguous and still in emission order.
-//  2. One workgroup per tile sorts its segment by the 32 depth bits, stably,
-//     entirely in registers + LDS (four 8-bit passes, passes whose digit is
-//     constant over the segment are skipped); segments longer than 4096 pairs
-//     fall back to the same passes ping-ponging through the spare global buffer.
+//  2. One workgroup per tile fetches the depth of each of its Gaussians (a
+//     gather from the per-Gaussian depth array, which stays in L2), sorts its
+//     segment by the 32 depth bits, stably, entirely in registers + LDS (four
+//     8-bit passes, passes whose digit is constant over the segment are
+//     skipped), and writes the 64-bit keys and the Gaussian list; segments
+//     longer than 4096 pairs run the same passes ping-ponging through global
+//     memory.
 //
 // Sorting stably by depth inside groups that are ordered by tile gives exactly
-// the order of a stable sort on (tile, depth).
+// the order of a stable sort on (tile, depth).  The same level-1 passes sort
+// the Morton codes of the nearest-neighbour search (knn.hip).
 #include "ngs_common.h"
 
 #define ST NGS_SORT_THREADS
@@ -29,9 +34,9 @@
 #define STILE NGS_SORT_TILE
 #define SWAVES (ST / 64)
 
-__device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, uint32_t mask)
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, uint32_t mask)
 {
-    return (uint32_t)(key >> shift) & mask;
+    return (key >> shift) & mask;
 }
 
 // Rank of this lane's item among the wave's items with the same digit that come earlier in input order, plus
@@ -53,7 +58,7 @@ __device__ __forceinline__ uint32_t wave_rank(uint32_t d, bool valid, uint32_t* 
     return rank;
 }
 
-__global__ __launch_bounds__(ST) void sort_hist_kernel(int64_t n, const uint64_t* __restrict__ keys, int shift,
+__global__ __launch_bounds__(ST) void sort_hist_kernel(int64_t n, const uint32_t* __restrict__ keys, int shift,
                                                        uint32_t mask, int nblocks, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t s_cnt[SWAVES][256];
@@ -103,9 +108,9 @@ __global__ __launch_bounds__(SCAN_T) void sort_scan_kernel(int nblocks, uint32_t
     if (tid == 0) totals[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint64_t* __restrict__ kin,
+__global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint32_t* __restrict__ kin,
                                                           const uint32_t* __restrict__ vin,
-                                                          uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                          uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                           int shift, uint32_t mask, int nblocks,
                                                           const uint32_t* __restrict__ hist,
                                                           const uint32_t* __restrict__ totals)
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint6
     __shared__ uint32_t s_gofs[256];         // global position of local slot 0 of each digit (minus s_start)
     __shared__ uint32_t s_wtot[SWAVES];
     __shared__ uint32_t s_gwtot[SWAVES];
-    __shared__ uint64_t s_key[STILE];
+    __shared__ uint32_t s_key[STILE];
     __shared__ uint32_t s_val[STILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * STILE;
@@ -125,14 +130,13 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint6
 
     // Wave-striped ownership keeps input order: wave w owns slots [w*64*SI, (w+1)*64*SI), item i of lane l is
     // slot w*64*SI + i*64 + l.
-    uint64_t key[SI];
-    uint32_t val[SI], rank[SI];
+    uint32_t key[SI], val[SI], rank[SI];
     const uint64_t lanes_below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int i = 0; i < SI; i++) {
         const int slot = wave * (64 * SI) + i * 64 + lane;
         const bool valid = slot < n_valid;
-        key[i] = valid ? kin[base + slot] : ~0ull;
+        key[i] = valid ? kin[base + slot] : ~0u;
         val[i] = valid ? vin[base + slot] : 0u;
     }
 #pragma unroll
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint6
     for (int i = 0; i < SI; i++) {
         const int pos = i * ST + tid;
         if (pos < n_valid) {
-            const uint64_t k = s_key[pos];
+            const uint32_t k = s_key[pos];
             const uint32_t g = s_gofs[digit_of(k, shift, mask)] + (uint32_t)pos;
             kout[g] = k;
             vout[g] = s_val[pos];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint6
 }
 
 // ---------------------------------------------------------------------------
-// Level 2: per-tile stable sort by the low 32 key bits.
+// Level 2: per-tile stable sort by the 32 depth bits.
 // ---------------------------------------------------------------------------
 // One 8-bit pass over the (up to 256*ITEMS) items a workgroup holds in registers: ranks them stably by digit and
 // returns each item's position among the workgroup's items; tot_out = items with digit `tid` in the workgroup.
@@ -234,6 +238,7 @@ __device__ __forceinline__ void block_rank_pass(const uint32_t (&key)[ITEMS], in
 // Segments with min_n < n <= 256*ITEMS: the whole segment lives in registers, no global traffic between passes.
 template <int ITEMS>
 __global__ __launch_bounds__(ST) void segment_sort_small_kernel(const uint2* __restrict__ ranges, int min_n,
+                                                                const float* __restrict__ depth,
                                                                 uint64_t* __restrict__ keys0,
                                                                 uint32_t* __restrict__ vals0)
 {
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(ST) void segment_sort_small_kernel(const uint2* __r
     const uint32_t tile = blockIdx.x;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (n <= min_n || n > CAP) return;  // block-uniform: another launch (or nobody, n <= 1) owns this tile
+    if (n <= min_n || n > CAP) return;  // block-uniform: another launch (or nobody, empty tile) owns this tile
     const size_t lo = range.x;
     const int quota = ((((n + SWAVES - 1) / SWAVES) + 63) / 64) * 64;  // slots per wave
     uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
@@ -257,8 +262,8 @@ __global__ __launch_bounds__(ST) void segment_sort_small_kernel(const uint2* __r
     for (int i = 0; i < ITEMS; i++) {
         const int slot = wave * quota + i * 64 + lane;
         const bool valid = i * 64 < quota && slot < n;
-        key[i] = valid ? (uint32_t)keys0[lo + slot] : ~0u;
         val[i] = valid ? vals0[lo + slot] : 0u;
+        key[i] = valid ? __float_as_uint(depth[val[i]]) : ~0u;
         if (valid) { k_or |= key[i]; k_and &= key[i]; }
     }
     // bits that differ somewhere in the segment
@@ -303,7 +308,8 @@ __global__ __launch_bounds__(ST) void segment_sort_small_kernel(const uint2* __r
 }
 
 // Segments longer than STILE pairs: the same four passes, chunk by chunk, ping-ponging through the spare buffer.
-__global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __restrict__ ranges, uint64_t* keys0,
+__global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __restrict__ ranges,
+                                                               const float* __restrict__ depth, uint64_t* keys0,
                                                                uint32_t* vals0, uint64_t* keys1, uint32_t* vals1)
 {
     __shared__ uint32_t s_cnt[SWAVES][256];
@@ -326,7 +332,11 @@ __global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __re
         // digit histogram of the whole segment -> running digit bases
         s_cnt[0][tid] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += ST) atomicAdd(&s_cnt[0][((uint32_t)ksrc[lo + i] >> shift) & 0xffu], 1u);
+        // the first pass has no keys yet: it builds them from the depth of each listed Gaussian
+        for (int i = tid; i < n; i += ST) {
+            const uint32_t k = pass == 0 ? __float_as_uint(depth[vsrc[lo + i]]) : (uint32_t)ksrc[lo + i];
+            atomicAdd(&s_cnt[0][(k >> shift) & 0xffu], 1u);
+        }
         __syncthreads();
         {
             const uint32_t c = s_cnt[0][tid];
@@ -345,8 +355,8 @@ __global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __re
             for (int i = 0; i < SI; i++) {
                 const int slot = wave * quota + i * 64 + lane;
                 const bool valid = slot < m;
-                key[i] = valid ? (uint32_t)ksrc[lo + c0 + slot] : ~0u;
                 val[i] = valid ? vsrc[lo + c0 + slot] : 0u;
+                key[i] = !valid ? ~0u : pass == 0 ? __float_as_uint(depth[val[i]]) : (uint32_t)ksrc[lo + c0 + slot];
             }
             uint32_t tot;
             block_rank_pass<SI>(key, shift, m, quota, s_cnt, s_start, s_wtot, pos, tot);
@@ -368,19 +378,19 @@ __global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __re
     }
 }
 
-static int tile_passes(int end_bit) { return end_bit > 32 ? (end_bit - 32 + 7) / 8 : 0; }
+static int tile_passes(int bits) { return (bits + 7) / 8; }
 
-int ngs_sort_input_buffer(int end_bit) { return tile_passes(end_bit) & 1; }
+int ngs_sort_input_buffer(int bits) { return tile_passes(bits) & 1; }
 
-void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint64_t* const keys[2], uint32_t* const vals[2],
-                               uint32_t* hist, uint32_t* totals, int end_bit)
+void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint32_t* const keys[2], uint32_t* const vals[2],
+                               uint32_t* hist, uint32_t* totals, int bits)
 {
     if (R <= 0) return;
     const int nblocks = (int)((R + STILE - 1) / STILE);
-    int cur = ngs_sort_input_buffer(end_bit);
-    for (int shift = 32; shift < end_bit; shift += 8) {
-        const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
-        const uint32_t mask = (1u << bits) - 1u;
+    int cur = ngs_sort_input_buffer(bits);
+    for (int shift = 0; shift < bits; shift += 8) {
+        const int width = bits - shift < 8 ? bits - shift : 8;
+        const uint32_t mask = (1u << width) - 1u;
         hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(ST), 0, s, R, keys[cur], shift, mask, nblocks, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(SCAN_T), 0, s, nblocks, hist, totals);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(ST), 0, s, R, keys[cur], vals[cur], keys[cur ^ 1],
@@ -389,11 +399,13 @@ void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint64_t* const keys[2]
     }
 }
 
-void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, uint64_t* const keys[2],
-                              uint32_t* const vals[2])
+void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint64_t* keys,
+                              uint64_t* spare_keys, uint32_t* const vals[2])
 {
-    // every tile is claimed by exactly one of the three launches (by segment length); the others exit at once
-    hipLaunchKernelGGL(segment_sort_small_kernel<8>, dim3(T), dim3(ST), 0, s, ranges, 1, keys[0], vals[0]);
-    hipLaunchKernelGGL(segment_sort_small_kernel<SI>, dim3(T), dim3(ST), 0, s, ranges, ST * 8, keys[0], vals[0]);
-    hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T), dim3(ST), 0, s, ranges, keys[0], vals[0], keys[1], vals[1]);
+    // every non-empty tile is claimed by exactly one of the three launches (by segment length); the others exit at
+    // once.  A single-entry tile is claimed too: its 64-bit key is only written here.
+    hipLaunchKernelGGL(segment_sort_small_kernel<8>, dim3(T), dim3(ST), 0, s, ranges, 0, depth, keys, vals[0]);
+    hipLaunchKernelGGL(segment_sort_small_kernel<SI>, dim3(T), dim3(ST), 0, s, ranges, ST * 8, depth, keys, vals[0]);
+    hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T), dim3(ST), 0, s, ranges, depth, keys, vals[0], spare_keys,
+                       vals[1]);
 }
