@@ -263,6 +263,12 @@ __global__ __launch_bounds__(ST) void segment_sort_small_kernel(const uint2* __r
         const int slot = wave * quota + i * 64 + lane;
         const bool valid = i * 64 < quota && slot < n;
         val[i] = valid ? vals0[lo + slot] : 0u;
+    }
+    // all list entries are on their way before the first dependent depth gather is issued
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const int slot = wave * quota + i * 64 + lane;
+        const bool valid = i * 64 < quota && slot < n;
         key[i] = valid ? __float_as_uint(depth[val[i]]) : ~0u;
         if (valid) { k_or |= key[i]; k_and &= key[i]; }
     }
