@@ -195,14 +195,16 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint3
 // One 8-bit pass over the (up to 256*ITEMS) items a workgroup holds in registers: ranks them stably by digit and
 // returns each item's position among the workgroup's items; tot_out = items with digit `tid` in the workgroup.
 // `quota` = slots owned by each wave (multiple of 64); item i of lane l of wave w is slot w*quota + i*64 + l.
-template <int ITEMS>
+template <int ITEMS, int WAVES = SWAVES>
 __device__ __forceinline__ void block_rank_pass(const uint32_t (&key)[ITEMS], int shift, int n_valid, int quota,
                                                 uint32_t (*s_cnt)[256], uint32_t* s_start, uint32_t* s_wtot,
                                                 uint32_t (&pos)[ITEMS], uint32_t& tot_out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool digit_thread = tid < 256;  // threads 0..255 also act for digit `tid` (all of them when WAVES == 4)
     const uint64_t lanes_below = (1ull << lane) - 1ull;
-    for (int w = 0; w < SWAVES; w++) s_cnt[w][tid] = 0;
+    if (digit_thread)
+        for (int w = 0; w < WAVES; w++) s_cnt[w][tid] = 0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
@@ -213,17 +215,20 @@ __device__ __forceinline__ void block_rank_pass(const uint32_t (&key)[ITEMS], in
     }
     __syncthreads();
     uint32_t tot = 0;
-    for (int w = 0; w < SWAVES; w++) {
-        const uint32_t c = s_cnt[w][tid];
-        s_cnt[w][tid] = tot;
-        tot += c;
-    }
+    if (digit_thread)
+        for (int w = 0; w < WAVES; w++) {
+            const uint32_t c = s_cnt[w][tid];
+            s_cnt[w][tid] = tot;
+            tot += c;
+        }
     const uint32_t incl = wave_incl_scan_u32(tot, lane);
-    if (lane == 63) s_wtot[wave] = incl;
+    if (lane == 63 && digit_thread) s_wtot[wave] = incl;
     __syncthreads();
-    uint32_t lbase = 0;
-    for (int w = 0; w < wave; w++) lbase += s_wtot[w];
-    s_start[tid] = lbase + incl - tot;
+    if (digit_thread) {
+        uint32_t lbase = 0;
+        for (int w = 0; w < wave; w++) lbase += s_wtot[w];
+        s_start[tid] = lbase + incl - tot;
+    }
     tot_out = tot;
     __syncthreads();
 #pragma unroll
@@ -235,18 +240,20 @@ __device__ __forceinline__ void block_rank_pass(const uint32_t (&key)[ITEMS], in
     }
 }
 
-// Segments with min_n < n <= 256*ITEMS: the whole segment lives in registers, no global traffic between passes.
-template <int ITEMS>
-__global__ __launch_bounds__(ST) void segment_sort_small_kernel(const uint2* __restrict__ ranges, int min_n,
-                                                                const float* __restrict__ depth,
-                                                                uint64_t* __restrict__ keys0,
-                                                                uint32_t* __restrict__ vals0)
+// Segments with min_n < n <= THREADS*ITEMS: the whole segment lives in registers, no global traffic between passes.
+// Longer segments get more threads rather than more items per thread: the passes are a chain of barriers, and a
+// workgroup's latency is what a launch with few such tiles waits for.
+template <int ITEMS, int THREADS>
+__global__ __launch_bounds__(THREADS) void segment_sort_small_kernel(const uint2* __restrict__ ranges, int min_n,
+                                                                     const float* __restrict__ depth,
+                                                                     uint64_t* __restrict__ keys0,
+                                                                     uint32_t* __restrict__ vals0)
 {
-    constexpr int CAP = ST * ITEMS;
-    __shared__ uint32_t s_cnt[SWAVES][256];
+    constexpr int CAP = THREADS * ITEMS, WAVES = THREADS / 64;
+    __shared__ uint32_t s_cnt[WAVES][256];
     __shared__ uint32_t s_start[256];
-    __shared__ uint32_t s_wtot[SWAVES];
-    __shared__ uint32_t s_red[2 * SWAVES];
+    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_red[2 * WAVES];
     __shared__ uint32_t s_key[CAP];
     __shared__ uint32_t s_val[CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(ST) void segment_sort_small_kernel(const uint2* __r
     const int n = (int)(range.y - range.x);
     if (n <= min_n || n > CAP) return;  // block-uniform: another launch (or nobody, empty tile) owns this tile
     const size_t lo = range.x;
-    const int quota = ((((n + SWAVES - 1) / SWAVES) + 63) / 64) * 64;  // slots per wave
+    const int quota = ((((n + WAVES - 1) / WAVES) + 63) / 64) * 64;  // slots per wave
     uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
     uint32_t k_or = 0u, k_and = ~0u;
 #pragma unroll
@@ -278,18 +285,18 @@ __global__ __launch_bounds__(ST) void segment_sort_small_kernel(const uint2* __r
         k_or |= (uint32_t)__shfl_xor((int)k_or, o, 64);
         k_and &= (uint32_t)__shfl_xor((int)k_and, o, 64);
     }
-    if (lane == 0) { s_red[wave] = k_or; s_red[SWAVES + wave] = k_and; }
+    if (lane == 0) { s_red[wave] = k_or; s_red[WAVES + wave] = k_and; }
     __syncthreads();
     uint32_t varying;
     {
         uint32_t o = 0u, a = ~0u;
-        for (int w = 0; w < SWAVES; w++) { o |= s_red[w]; a &= s_red[SWAVES + w]; }
+        for (int w = 0; w < WAVES; w++) { o |= s_red[w]; a &= s_red[WAVES + w]; }
         varying = o ^ a;
     }
     for (int shift = 0; shift < 32; shift += 8) {
         if (((varying >> shift) & 0xffu) == 0u) continue;  // digit constant over the segment (block-uniform)
         uint32_t tot;
-        block_rank_pass<ITEMS>(key, shift, n, quota, s_cnt, s_start, s_wtot, pos, tot);
+        block_rank_pass<ITEMS, WAVES>(key, shift, n, quota, s_cnt, s_start, s_wtot, pos, tot);
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
             const int slot = wave * quota + i * 64 + lane;
@@ -410,8 +417,9 @@ void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const f
 {
     // every non-empty tile is claimed by exactly one of the three launches (by segment length); the others exit at
     // once.  A single-entry tile is claimed too: its 64-bit key is only written here.
-    hipLaunchKernelGGL(segment_sort_small_kernel<8>, dim3(T), dim3(ST), 0, s, ranges, 0, depth, keys, vals[0]);
-    hipLaunchKernelGGL(segment_sort_small_kernel<SI>, dim3(T), dim3(ST), 0, s, ranges, ST * 8, depth, keys, vals[0]);
+    hipLaunchKernelGGL((segment_sort_small_kernel<8, ST>), dim3(T), dim3(ST), 0, s, ranges, 0, depth, keys, vals[0]);
+    hipLaunchKernelGGL((segment_sort_small_kernel<8, 2 * ST>), dim3(T), dim3(2 * ST), 0, s, ranges, ST * 8, depth, keys,
+                       vals[0]);
     hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T), dim3(ST), 0, s, ranges, depth, keys, vals[0], spare_keys,
                        vals[1]);
 }
