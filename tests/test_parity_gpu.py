@@ -117,6 +117,23 @@ def test_forward_backward_matches_oracle(name, dgr, oracle):
     check_grads(h["grads"], og, scale=float(c["W"] * c["H"]))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_configurations(seed, dgr, oracle):
+    """Random image sizes (not multiples of the tile size), counts, footprints, SH degrees and eye positions."""
+    rng = np.random.RandomState(1000 + seed)
+    D = int(rng.randint(0, 4))
+    lo = float(rng.uniform(-5.5, -2.5))
+    c = case(P=int(rng.randint(30, 4000)), W=int(rng.randint(17, 260)), H=int(rng.randint(17, 200)), D=D,
+             M=int(rng.choice([(D + 1) ** 2, 16])), log_scale=(lo, lo + float(rng.uniform(0.2, 2.0))), seed=seed,
+             eye=(float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-4.5, -0.8))),
+             bg=tuple(float(v) for v in rng.uniform(0, 1, 3)))
+    dL = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(seed))
+    o = oracle_forward(oracle, c)
+    h = run_hip(dgr, c, dL_dpix=dL)
+    check_forward(o, h, exact_pixels=False)
+    check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=float(c["W"] * c["H"]))
+
+
 def test_more_than_65536_tiles(dgr, oracle):
     """4112 x 4112 pixels = 257 x 257 tiles: tile ids need 17 bits, so the global part of the sort runs three radix
     passes (the other cases run one or two) and the tile coordinates use the upper range of their 16-bit fields."""
