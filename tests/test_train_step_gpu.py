@@ -196,3 +196,36 @@ def test_training_iterations_match_pytorch_assembly(C):
         assert float(close.float().mean()) > 0.995, k
         assert float(diff.max()) <= 6.5 * lr_of[k], k
     assert int((tr.denom > 0).sum()) > 0 and int(tr.max_radii2D.max()) > 0
+
+
+def test_training_fits_a_rendered_target(C):
+    """End to end: the image of a scene is the target, a copy of that scene with scrambled colours and dimmed
+    opacities is trained on it from three views; the loss has to fall substantially and monotonically enough."""
+    from neuralgaussiansplatting_amd import view_parallel
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C as dC
+    P, W, H, D = 3000, 128, 96, 3
+    truth = synthetic.make_scene(P, D, (-3.6, -2.8), (1.3, 1.0, 1.3), seed=12, sh_coeffs=16).to(DEV)
+    cams = [make_camera(W, H, synthetic.FOVX, e, device=DEV) for e in ((0.7, 0.5, -4.0), (-1.5, 0.4, -3.6), (1.4, -0.3, -3.7))]
+    bg = torch.zeros(3, device=DEV)
+    e = torch.empty(0)
+    targets = []
+    for cam in cams:
+        tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        out = dC.rasterize_gaussians(bg, truth.means3D, e, truth.opacities, truth.scales, truth.rotations, 1.0, e,
+                                     cam.world_view_transform, cam.full_proj_transform, tanx, tany, H, W, truth.shs, D,
+                                     cam.camera_center, False, False)
+        targets.append(out[1].clone())
+    start = synthetic.make_scene(P, D, (-3.6, -2.8), (1.3, 1.0, 1.3), seed=12, sh_coeffs=16)
+    g = torch.Generator().manual_seed(5)
+    start.shs[:, 0, :] = torch.rand(P, 3, generator=g) * 2.0 - 1.0
+    start.shs[:, 1:, :] = 0.0
+    start.opacities.mul_(0.5)
+    tr = train_step.GaussianTrainer(start, DEV)
+    losses = []
+    for it in range(90):
+        cam, gt = cams[it % 3], targets[it % 3]
+        terms, _, _ = tr.step(cam, gt, bg, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5))
+        losses.append(float(terms[2]))
+    first, last = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
+    assert last < 0.5 * first, (first, last)
+    assert all(torch.isfinite(t).all() for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw))
