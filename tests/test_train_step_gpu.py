@@ -229,3 +229,45 @@ def test_training_fits_a_rendered_target(C):
     first, last = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
     assert last < 0.5 * first, (first, last)
     assert all(torch.isfinite(t).all() for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw))
+
+
+def _two_rank_trainer_worker(rank, port, exchange, ret):
+    """Two gloo ranks sharing the one GPU: each trains on its own view; the gradient exchange (factored or dense)
+    must leave both parameter replicas bit-identical."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        P, W, H, D = 2500, 96, 64, 3
+        sc = synthetic.make_scene(P, D, (-3.8, -3.0), (1.3, 1.3, 1.3), seed=8, sh_coeffs=16)
+        cam = make_camera(W, H, synthetic.FOVX, ((0.7, 0.5, -4.0), (-1.8, 0.4, -3.5))[rank], device=DEV)
+        gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(60 + rank)).to(DEV)
+        bg = torch.zeros(3, device=DEV)
+        tr = train_step.GaussianTrainer(sc, DEV, factored_exchange=exchange == "factored")
+        for _ in range(3):
+            tr.step(cam, gt, bg, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5))
+        tr.sync_densification_stats()
+        torch.cuda.synchronize()
+        state = [t.detach().cpu() for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw,
+                                            tr.xyz_gradient_accum, tr.denom, tr.max_radii2D.float())]
+        flat = torch.cat([t.reshape(-1).double() for t in state])
+        both = [torch.empty_like(flat) for _ in range(2)]
+        dist.all_gather(both, flat)
+        moved = float((tr.features.cpu() - sc.shs).abs().max()) > 0
+        ret[rank] = bool(torch.equal(both[0], both[1]) and torch.isfinite(flat).all() and moved)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["factored", "dense"])
+def test_two_rank_training_keeps_replicas_identical(exchange, C):
+    import os
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 35500 + os.getpid() % 2000 + (7 if exchange == "dense" else 0)
+    mp.spawn(_two_rank_trainer_worker, args=(port, exchange, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
