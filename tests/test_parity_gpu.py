@@ -134,6 +134,32 @@ def test_random_configurations(seed, dgr, oracle):
     check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=float(c["W"] * c["H"]))
 
 
+def test_nonfinite_inputs_neither_hang_nor_fault(dgr):
+    """NaN / inf / zero / huge values in single Gaussians: the call must return (no endless loop, no GPU fault), and
+    the Gaussians that were not touched still get finite gradients."""
+    dev = torch.device("cuda:0")
+    c = case(P=2000, W=96, H=64, D=3, M=16, seed=77)
+    sc, cam = c["scene"], c["cam"]
+    means, scales, op, rots, shs = (t.clone() for t in (sc.means3D, sc.scales, sc.opacities, sc.rotations, sc.shs))
+    means[5] = float("nan"); means[6, 0] = float("inf"); scales[7] = float("nan"); scales[8] = 1e30; scales[9] = 0.0
+    op[10] = float("nan"); op[11] = 1.0; op[12] = 0.0; rots[13] = 0.0; rots[14] = float("nan")
+    shs[15] = float("nan"); shs[16] = 1e30
+    g = lambda t: t.to(dev)
+    e = torch.empty(0)
+    R, color, radii, geom, binning, img = dgr._C.rasterize_gaussians(
+        g(c["bg"]), g(means), e, g(op), g(scales), g(rots), 1.0, e, g(cam.world_view_transform),
+        g(cam.full_proj_transform), c["tanfovx"], c["tanfovy"], c["H"], c["W"], g(shs), 3, g(cam.camera_center), False,
+        False)
+    dL = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(1)).to(dev)
+    res = dgr._C.rasterize_gaussians_backward(
+        g(c["bg"]), g(means), radii, e, g(scales), g(rots), 1.0, e, g(cam.world_view_transform),
+        g(cam.full_proj_transform), c["tanfovx"], c["tanfovy"], dL, g(shs), 3, g(cam.camera_center), geom, R, binning,
+        img, False)
+    torch.cuda.synchronize()
+    assert R > 0 and color.shape == (3, c["H"], c["W"])
+    assert float(torch.isfinite(res[3]).all(dim=1).float().mean()) > 0.98
+
+
 def test_more_than_65536_tiles(dgr, oracle):
     """4112 x 4112 pixels = 257 x 257 tiles: tile ids need 17 bits, so the global part of the sort runs three radix
     passes (the other cases run one or two) and the tile coordinates use the upper range of their 16-bit fields."""
