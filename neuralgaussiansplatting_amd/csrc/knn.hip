@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256) void knn_bounds_kernel(int P, const float* __r
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const float c = points[(size_t)3 * i + a];
-            lo[a] = fminf(lo[a], c);
-            hi[a] = fmaxf(hi[a], c);
+            if (isfinite(c)) {  // an infinite coordinate would flatten every Morton code of its axis to zero
+                lo[a] = fminf(lo[a], c);
+                hi[a] = fmaxf(hi[a], c);
+            }
         }
     }
 #pragma unroll
@@ -128,9 +130,16 @@ __global__ __launch_bounds__(256) void knn_gather_kernel(int P, const float* __r
     float3 lo = make_float3(FLT_MAX, FLT_MAX, FLT_MAX), hi = make_float3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
     if (i < P) {
         const uint32_t src = order[i];
-        const float3 p = make_float3(points[(size_t)3 * src], points[(size_t)3 * src + 1], points[(size_t)3 * src + 2]);
+        float3 p = make_float3(points[(size_t)3 * src], points[(size_t)3 * src + 1], points[(size_t)3 * src + 2]);
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            lo = hi = p;
+        } else {
+            // The reference's insertion ignores a NaN distance (simple_knn.cu:138), i.e. such a point is nobody's
+            // neighbour: moved to infinity it yields infinite distances, which are never inserted either, and it
+            // stays out of the bounding boxes.
+            p = make_float3(INFINITY, INFINITY, INFINITY);
+        }
         sorted[i] = make_float4(p.x, p.y, p.z, __uint_as_float(src));
-        lo = hi = p;
     }
     lo.x = wave_min_f(lo.x); lo.y = wave_min_f(lo.y); lo.z = wave_min_f(lo.z);
     hi.x = wave_max_f(hi.x); hi.y = wave_max_f(hi.y); hi.z = wave_max_f(hi.z);
@@ -214,10 +223,13 @@ __global__ __launch_bounds__(256) void knn_search_kernel(int P, int L, int S, co
     const int own = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // wave-uniform
     if (own >= L) return;
     const int n_own = min(KNN_LEAF, P - own * KNN_LEAF);
-    const bool valid = lane < n_own;
+    const bool present = lane < n_own;
     float4 me = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (valid) me = sorted[(size_t)own * KNN_LEAF + lane];
+    if (present) me = sorted[(size_t)own * KNN_LEAF + lane];
     const float3 q = make_float3(me.x, me.y, me.z);
+    // A point with a non-finite coordinate has no defined neighbours; it must not drive the search either (its
+    // rejection radius would never shrink and its wave would visit every leaf).  It keeps what its own leaf gave.
+    const bool valid = present && isfinite(q.x) && isfinite(q.y) && isfinite(q.z);
     float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
     // the wave's own leaf first: it yields the rejection radius (the reference looks at the 3 neighbours either side
     // in Morton order for that, simple_knn.cu:156-163)
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(256) void knn_search_kernel(int P, int L, int S, co
             }
         }
     }
-    if (valid) mean_dist2[__float_as_uint(me.w)] = (b0 + b1 + b2) / 3.0f;  // simple_knn.cu:182
+    if (present) mean_dist2[__float_as_uint(me.w)] = (b0 + b1 + b2) / 3.0f;  // simple_knn.cu:182
 }
 
 struct KnnLayout {

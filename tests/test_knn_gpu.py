@@ -74,3 +74,18 @@ def test_create_from_pcd(dist2):
     np.testing.assert_allclose(SH2RGB(m._features_dc[:, 0, :]).detach().cpu().numpy(), pcd.colors, atol=1e-6)
     assert torch.allclose(m.get_opacity, torch.full((5000, 1), 0.1, device=DEV))
     assert torch.equal(m.get_rotation, torch.tensor([[1.0, 0, 0, 0]], device=DEV).expand(5000, 4))
+
+
+def test_knn_nonfinite_points_do_not_stall_the_search(dist2, oracle):
+    """A NaN or infinite coordinate has no defined neighbours; such points must not make their wave walk every leaf
+    (thousands of them would take minutes), and the finite points' results must not change."""
+    pts = knn_points("uniform", 200000, seed=4)
+    bad = np.random.RandomState(1).choice(pts.shape[0], 3000, replace=False)
+    dirty = pts.copy()
+    dirty[bad[:1500], 0] = np.nan
+    dirty[bad[1500:], 2] = np.inf
+    got = dist2(torch.tensor(dirty, device=DEV)).cpu().numpy()
+    keep = np.ones(pts.shape[0], bool)
+    keep[bad] = False
+    want = oracle.knn_mean_dist2(pts[keep])
+    np.testing.assert_array_equal(got[keep], want)
