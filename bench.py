@@ -2,7 +2,7 @@
 """Benchmark of the rasterizer hot path: forward + backward of one camera view
 per GPU on a synthetic scene, through the C ABI of libngs_rasterizer.so.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
@@ -12,6 +12,11 @@ inputs already resident in HBM; with N > 1 each rank renders its own view of
 the replicated scene and the step ends with the exchange (RCCL) that leaves the
 sum over views of the per-Gaussian gradients on every rank (see
 neuralgaussiansplatting_amd/view_parallel.py).  Rank 0 prints one JSON line.
+
+Side loops reported in the same line: whole training iterations (at most 20 from the initial scene unless
+--train-steps says otherwise: fitting the random target changes the scene and with it the work per pixel), the
+index-map operator and the nearest-neighbour initialisation.  Python's garbage collector is held off during the
+timed loops; its full collections take tens of milliseconds and would land in whichever loop is running.
 """
 import argparse
 import gc
