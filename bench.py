@@ -21,7 +21,6 @@ timed loops; its full collections take tens of milliseconds and would land in wh
 import argparse
 import gc
 import json
-import math
 import os
 import sys
 import time

@@ -13,7 +13,6 @@ combined loss of train.py:90-92 with its gradient wrt the image, and the
 position learning-rate schedule (utils/general_utils.py:29-61).
 Only inputs and outputs are stored.
 """
-import math
 import os
 import sys
 

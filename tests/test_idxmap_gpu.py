@@ -1,7 +1,6 @@
 """GPU parity of the index-map operators (through the C ABI) against the checker's restatement of the reference's
 scan / key / sort / range pipeline.  Bar: index map, depth map and the copied features bit-exact; view direction
 and its positional encoding within 2e-6 (device vs host sin/cos/sqrt); the backward sum within float addition order."""
-import math
 
 import numpy as np
 import pytest

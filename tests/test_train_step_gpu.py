@@ -201,7 +201,6 @@ def test_training_iterations_match_pytorch_assembly(C):
 def test_training_fits_a_rendered_target(C):
     """End to end: the image of a scene is the target, a copy of that scene with scrambled colours and dimmed
     opacities is trained on it from three views; the loss has to fall substantially and monotonically enough."""
-    from neuralgaussiansplatting_amd import view_parallel
     from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C as dC
     P, W, H, D = 3000, 128, 96, 3
     truth = synthetic.make_scene(P, D, (-3.6, -2.8), (1.3, 1.0, 1.3), seed=12, sh_coeffs=16).to(DEV)

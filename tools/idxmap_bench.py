@@ -1,8 +1,7 @@
-import sys, time, math, torch
+import sys, time, torch
 sys.path.insert(0, ".")
 from neuralgaussiansplatting_amd import synthetic
 from neuralgaussiansplatting_amd.rasterizer2 import _C as r2c
-from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C
 dev = torch.device("cuda:0")
 P, W, H, D, M, _, _ = synthetic.CONFIGS["c4"]
 scene, W, H = synthetic.make_config("c4", seed=1234)
