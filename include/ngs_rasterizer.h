@@ -178,7 +178,9 @@ int ngs_sh_gradient_from_views(int P, int D, int M, int V, const float* means3D,
  * returns it; the activation's backward is applied here, raw[] is updated in place and activated[] receives the new
  * activated values for the next forward pass.  When xyz_gradient_accum is not NULL the densification statistics
  * are updated as well for Gaussians with radii > 0: xyz_gradient_accum += |dL_dmean2D.xy|, denom += 1
- * (gaussian_model.py:550-552), max_radii2D = max(max_radii2D, radii) (train.py:115).
+ * (gaussian_model.py:550-552), max_radii2D = max(max_radii2D, radii) (train.py:115).  step[] holds one count per
+ * group: torch keeps it per parameter, and the reference's opacity reset (gaussian_model.py:331-334 with train.py:122-127)
+ * makes the opacity group miss a step the other two take.
  */
 size_t ngs_loss_workspace_bytes(int width, int height);
 int ngs_l1_ssim_loss(int width, int height, float lambda_dssim, const float* image, const float* gt_image,
@@ -188,7 +190,7 @@ int ngs_adam_step(long long n, float* param, const float* grad, float* exp_avg, 
                   float grad_scale, void* stream);
 int ngs_adam_step_activated(int P, float* const raw[3], const float* const grad[3], float* const exp_avg[3],
                             float* const exp_avg_sq[3], float* const activated[3], const double lr[3], double beta1,
-                            double beta2, double eps, int step, float grad_scale, const float* dL_dmean2D,
+                            double beta2, double eps, const int step[3], float grad_scale, const float* dL_dmean2D,
                             const int* radii, float* xyz_gradient_accum, float* denom, int* max_radii2D,
                             void* stream);
 

@@ -576,14 +576,16 @@ extern "C" int ngs_adam_step(long long n, float* param, const float* grad, float
 extern "C" int ngs_adam_step_activated(int P, float* const raw[3], const float* const grad[3],
                                        float* const exp_avg[3], float* const exp_avg_sq[3],
                                        float* const activated[3], const double lr[3], double beta1, double beta2,
-                                       double eps, int step, float grad_scale, const float* dL_dmean2D,
+                                       double eps, const int step[3], float grad_scale, const float* dL_dmean2D,
                                        const int* radii, float* xyz_gradient_accum, float* denom, int* max_radii2D,
                                        void* stream)
 {
     g_err[0] = 0;
     if (P < 0) return fail("ngs_adam_step_activated", "bad size");
-    if (!adam_args_ok(beta1, beta2, eps, step))
-        return fail("ngs_adam_step_activated", "bad Adam constants or step < 1");
+    if (!step) return fail("ngs_adam_step_activated", "missing required pointer");
+    for (int i = 0; i < 3; i++)
+        if (!adam_args_ok(beta1, beta2, eps, step[i]))
+            return fail("ngs_adam_step_activated", "bad Adam constants or step < 1");
     if (P == 0) return 0;
     if (!raw || !grad || !exp_avg || !exp_avg_sq || !activated || !lr)
         return fail("ngs_adam_step_activated", "missing required pointer");

@@ -219,7 +219,7 @@ void ngs_launch_adam_flat(hipStream_t s, long long n, float* param, const float*
                           double beta2, double eps, int step, float grad_scale);
 void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const float* const grad[3],
                                float* const exp_avg[3], float* const exp_avg_sq[3], float* const activated[3],
-                               const double lr[3], double beta1, double beta2, double eps, int step,
+                               const double lr[3], double beta1, double beta2, double eps, const int step[3],
                                float grad_scale, const float* dL_dmean2D, const int* radii, float* grad_accum,
                                float* denom, int* max_radii);
 
@@ -362,12 +362,18 @@ __device__ __forceinline__ void stream_store4(float* p, float4 v)
     __builtin_nontemporal_store((ngs_v4f){v.x, v.y, v.z, v.w}, (ngs_v4f*)p);
 }
 
-__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float step, const AdamConst& k)
+// bc2_sqrt is passed apart from k for callers whose parameter groups have taken different numbers of steps
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float step, float bc2_sqrt,
+                                             const AdamConst& k)
 {
     m = m + k.one_minus_beta1 * (g - m);
     v = v * k.beta2 + k.one_minus_beta2 * g * g;
-    const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+    const float denom = sqrtf(v) / bc2_sqrt + k.eps;
     return p - step * (m / denom);
+}
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float step, const AdamConst& k)
+{
+    return adam_update(p, g, m, v, step, k.bc2_sqrt, k);
 }
 
 // Spherical-harmonics constants (cuda_rasterizer/auxiliary.h:22-39).

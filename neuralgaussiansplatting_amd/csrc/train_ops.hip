@@ -333,7 +333,8 @@ struct ActivatedGroup {
     float* exp_avg;
     float* exp_avg_sq;
     float* activated;  // activated value for the next forward pass, written here
-    float step;        // float(lr / (1 - beta1^t))
+    float step;        // float(lr / (1 - beta1^t)), t = the number of steps THIS group has taken
+    float bc2_sqrt;    // float(sqrt(1 - beta2^t))
 };
 
 // One lane per Gaussian: opacity (sigmoid), scale (exp) and rotation (normalise), each with the backward of its
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void adam_activated_kernel(int P, ActivatedGro
         const float act = 1.0f / (1.0f + expf(-raw));
         const float g = (op.grad[i] * k.grad_scale) * ((1.0f - act) * act);
         float m = op.exp_avg[i], v = op.exp_avg_sq[i];
-        const float nr = adam_update(raw, g, m, v, op.step, k);
+        const float nr = adam_update(raw, g, m, v, op.step, op.bc2_sqrt, k);
         op.raw[i] = nr;
         op.exp_avg[i] = m;
         op.exp_avg_sq[i] = v;
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void adam_activated_kernel(int P, ActivatedGro
         const float raw = sc.raw[j];
         const float g = (sc.grad[j] * k.grad_scale) * expf(raw);
         float m = sc.exp_avg[j], v = sc.exp_avg_sq[j];
-        const float nr = adam_update(raw, g, m, v, sc.step, k);
+        const float nr = adam_update(raw, g, m, v, sc.step, sc.bc2_sqrt, k);
         sc.raw[j] = nr;
         sc.exp_avg[j] = m;
         sc.exp_avg_sq[j] = v;
@@ -383,10 +384,10 @@ __global__ __launch_bounds__(256) void adam_activated_kernel(int P, ActivatedGro
                                       (g.w - a.w * dot) / len);
         float4 m = ((const float4*)ro.exp_avg)[i], v = ((const float4*)ro.exp_avg_sq)[i];
         float4 nr;
-        nr.x = adam_update(raw.x, gr.x, m.x, v.x, ro.step, k);
-        nr.y = adam_update(raw.y, gr.y, m.y, v.y, ro.step, k);
-        nr.z = adam_update(raw.z, gr.z, m.z, v.z, ro.step, k);
-        nr.w = adam_update(raw.w, gr.w, m.w, v.w, ro.step, k);
+        nr.x = adam_update(raw.x, gr.x, m.x, v.x, ro.step, ro.bc2_sqrt, k);
+        nr.y = adam_update(raw.y, gr.y, m.y, v.y, ro.step, ro.bc2_sqrt, k);
+        nr.z = adam_update(raw.z, gr.z, m.z, v.z, ro.step, ro.bc2_sqrt, k);
+        nr.w = adam_update(raw.w, gr.w, m.w, v.w, ro.step, ro.bc2_sqrt, k);
         ((float4*)ro.raw)[i] = nr;
         ((float4*)ro.exp_avg)[i] = m;
         ((float4*)ro.exp_avg_sq)[i] = v;
@@ -457,7 +458,7 @@ void ngs_launch_adam_flat(hipStream_t s, long long n, float* param, const float*
 
 void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const float* const grad[3],
                                float* const exp_avg[3], float* const exp_avg_sq[3], float* const activated[3],
-                               const double lr[3], double beta1, double beta2, double eps, int step,
+                               const double lr[3], double beta1, double beta2, double eps, const int step[3],
                                float grad_scale,
                                const float* dL_dmean2D, const int* radii, float* grad_accum, float* denom,
                                int* max_radii)
@@ -469,9 +470,10 @@ void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const 
         g[i].exp_avg = exp_avg[i];
         g[i].exp_avg_sq = exp_avg_sq[i];
         g[i].activated = activated[i];
-        g[i].step = ngs_adam_step_size(lr[i], beta1, step);
+        g[i].step = ngs_adam_step_size(lr[i], beta1, step[i]);
+        g[i].bc2_sqrt = ngs_adam_const(beta1, beta2, eps, step[i], grad_scale).bc2_sqrt;
     }
     hipLaunchKernelGGL(adam_activated_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g[0], g[1], g[2],
-                       ngs_adam_const(beta1, beta2, eps, step, grad_scale), dL_dmean2D, radii, grad_accum, denom,
+                       ngs_adam_const(beta1, beta2, eps, step[0], grad_scale), dL_dmean2D, radii, grad_accum, denom,
                        max_radii);
 }

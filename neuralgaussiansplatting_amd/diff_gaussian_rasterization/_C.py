@@ -354,7 +354,7 @@ def adam_step_activated(raw, grad, exp_avg, exp_avg_sq, activated, lrs, step, be
     the gradients wrt the ACTIVATED values; raw values and Adam state are updated in place and ``activated``
     receives sigmoid / exp / normalise of the new raw values.  ``densify`` = (dL_dmean2D [P,3], radii [P] int32,
     xyz_gradient_accum [P,1], denom [P,1], max_radii2D [P] int32) also updates the densification statistics
-    (gaussian_model.py:550-552, train.py:115)."""
+    (gaussian_model.py:550-552, train.py:115).  ``step`` is one count for all three groups or a 3-tuple."""
     _require_gpu(raw[0])
     dev = raw[0].device
     P = raw[0].numel()
@@ -365,6 +365,7 @@ def adam_step_activated(raw, grad, exp_avg, exp_avg_sq, activated, lrs, step, be
                 raise RuntimeError("opacity/scaling/rotation tensors must be contiguous float32 [P,1], [P,3], [P,4] "
                                    "on %s" % dev)
     arr = lambda group: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in group])
+    steps = [int(x) for x in step] if isinstance(step, (tuple, list)) else [int(step)] * 3
     null = ctypes.c_void_p(0)
     d = [null] * 5
     if densify is not None:
@@ -380,7 +381,8 @@ def adam_step_activated(raw, grad, exp_avg, exp_avg_sq, activated, lrs, step, be
         _check(lib().ngs_adam_step_activated(
             P, arr(raw), arr(grad), arr(exp_avg), arr(exp_avg_sq), arr(activated),
             (ctypes.c_double * 3)(*[float(x) for x in lrs]), ctypes.c_double(betas[0]), ctypes.c_double(betas[1]),
-            ctypes.c_double(eps), int(step), ctypes.c_float(grad_scale), d[0], d[1], d[2], d[3], d[4], _stream(dev)))
+            ctypes.c_double(eps), (ctypes.c_int * 3)(*steps), ctypes.c_float(grad_scale), d[0], d[1], d[2], d[3], d[4],
+            _stream(dev)))
 
 
 def profile_enable(on=True):

@@ -6,7 +6,7 @@ on scales, ``sigmoid`` on opacity, L2 normalisation on quaternions, DC and
 higher SH bands concatenated.  Also the two ends of a run from a point cloud:
 ``create_from_pcd`` (initial scales from the nearest-neighbour distances,
 :150-183) and ``save_ply`` / ``load_ply`` in the reference's file layout
-(:289-392).  Densification and optimiser set-up are not provided here.
+(:289-392).  Densification and the optimiser live with the training step (``train_step.GaussianTrainer``).
 """
 import os
 

@@ -1,7 +1,8 @@
-"""One training iteration around the rasterizer, the counterpart of the reference's loop body (train.py:67-128)
-for a fixed set of Gaussians: learning-rate schedule, render, L1 + D-SSIM loss, backward, (multi-GPU: gradient
-exchange), Adam.  Densification, pruning and opacity reset change the number of Gaussians and are not part of it;
-the statistics they consume (gaussian_model.py:550-552, train.py:115) are maintained.
+"""One training iteration around the rasterizer, the counterpart of the reference's loop body (train.py:67-128):
+learning-rate schedule, SH degree schedule, render, L1 + D-SSIM loss, backward, (multi-GPU: gradient exchange),
+densification statistics, clone / split / prune and opacity reset on the reference's schedule, Adam.
+``GaussianTrainer.step`` is the iteration for a fixed set of Gaussians (what the benchmarks time);
+``GaussianTrainer.train_iteration`` wraps it with everything that changes their number or resets them.
 
 What differs from the reference's way of running the same arithmetic:
 
@@ -33,6 +34,13 @@ class OptimizationParams:
     scaling_lr = 0.005
     rotation_lr = 0.001
     lambda_dssim = 0.2
+    iterations = 30_000
+    percent_dense = 0.01
+    densification_interval = 100
+    opacity_reset_interval = 3000
+    densify_from_iter = 500
+    densify_until_iter = 15_000
+    densify_grad_threshold = 0.0002
 
 
 def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
@@ -81,19 +89,40 @@ class GaussianTrainer:
             p = getattr(self, name)
             self.state[name] = (torch.zeros_like(p), torch.zeros_like(p))
         self.iteration = 0
+        # torch.optim.Adam counts steps per parameter, and the reference's parameters miss the step of an iteration
+        # in which they were replaced (densification: all of them; opacity reset: the opacities) -- train.py:113-128
+        self.adam_steps = dict.fromkeys(("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw"), 0)
+        self.max_sh_degree = max(int(round(math.sqrt(self.M))) - 1, self.sh_degree)
+        self.extras = {}  # further per-Gaussian rows (normals, feature vectors ...) that follow clone / split / prune
         world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
                                                        torch.distributed.is_initialized()) else 1
         self.world = world
-        self.exchange = (view_parallel.FactoredGradientExchange(self.P, self.M, dev) if world > 1 and factored_exchange
-                         else view_parallel.GradientBucket(self.P, self.M, dev))
-        self.densify = None
-        if densify_stats:
-            self.xyz_gradient_accum = torch.zeros((self.P, 1), device=dev)
-            self.denom = torch.zeros((self.P, 1), device=dev)
-            self.max_radii2D = torch.zeros(self.P, dtype=torch.int32, device=dev)
+        self.factored_exchange = factored_exchange
         self.densify_stats = densify_stats
         self._workspace = None
         self._dL_dpix = None
+        self._resized()
+
+    def _resized(self):
+        """(Re)build everything whose size follows the number of Gaussians: gradient buffers, statistics."""
+        dev = self.xyz.device
+        self.P = self.xyz.shape[0]
+        self.exchange = (view_parallel.FactoredGradientExchange(self.P, self.M, dev)
+                         if self.world > 1 and self.factored_exchange
+                         else view_parallel.GradientBucket(self.P, self.M, dev))
+        if self.densify_stats:  # gaussian_model.py:486-488
+            self.xyz_gradient_accum = torch.zeros((self.P, 1), device=dev)
+            self.denom = torch.zeros((self.P, 1), device=dev)
+            self.max_radii2D = torch.zeros(self.P, dtype=torch.int32, device=dev)
+
+    def _activate(self):
+        self.opacities = torch.sigmoid(self.opacity_raw)
+        self.scales = torch.exp(self.scaling_raw)
+        self.rotations = torch.nn.functional.normalize(self.rotation_raw)
+
+    def oneupSHdegree(self):  # gaussian_model.py:146-148
+        if self.sh_degree < self.max_sh_degree:
+            self.sh_degree += 1
 
     def sync_densification_stats(self, group=None):
         """Totals over all ranks' views, in place (see ``view_parallel.sync_densification_stats``)."""
@@ -111,10 +140,13 @@ class GaussianTrainer:
                         o.position_lr_final * self.spatial_lr_scale, lr_delay_mult=o.position_lr_delay_mult,
                         max_steps=o.position_lr_max_steps)
 
-    def step(self, cam, gt_image, bg, tanfovx, tanfovy):
-        """One iteration on this rank's view.  Returns (loss_terms, color, radii); loss_terms stays on the device."""
+    def step(self, cam, gt_image, bg, tanfovx, tanfovy, optimize=True, hold_opacity=False, collect_stats=True):
+        """One iteration on this rank's view.  Returns (loss_terms, color, radii); loss_terms stays on the device.
+        ``optimize=False`` renders and differentiates (statistics are still gathered) but moves no parameter;
+        ``hold_opacity`` leaves the opacities alone while everything else takes its step."""
         self.iteration += 1
         it, o = self.iteration, self.opt
+        stats = self.densify_stats and collect_stats
         H, W = int(cam.image_height), int(cam.image_width)
         if self._workspace is None or self._dL_dpix is None or self._dL_dpix.shape != (3, H, W):
             self._workspace = torch.empty(_C.loss_workspace_floats(W, H), dtype=torch.float32, device=self.xyz.device)
@@ -131,31 +163,154 @@ class GaussianTrainer:
         # gradient is consumed where it is produced instead of travelling through memory to a separate Adam kernel.
         scale = 1.0 / self.world  # the batch loss is the mean over the views of all ranks
         factored = isinstance(self.exchange, view_parallel.FactoredGradientExchange)
+        if not optimize:
+            color, radii, aux = view_parallel.forward_backward(scene, cam, bg, loss_grad, self.exchange, tanfovx,
+                                                               tanfovy)
+            if stats:
+                self._add_densification_stats(aux["dL_dmeans2D"], radii)
+            return terms["loss"], color, radii
+        steps = self.adam_steps
+        for name in steps:
+            if not (hold_opacity and name == "opacity_raw"):
+                steps[name] += 1
         fused_sh = self.M == 16 and (self.world == 1 or factored)
         sh_adam = None
         if fused_sh:
             m, v = self.state["features"]
             sh_adam = dict(param=self.features, exp_avg=m, exp_avg_sq=v, lr_dc=o.feature_lr,
-                           lr_rest=o.feature_lr / 20.0, step=it, grad_scale=scale)
+                           lr_rest=o.feature_lr / 20.0, step=steps["features"], grad_scale=scale)
         # one rank: inside the backward pass; several ranks: inside the kernel that rebuilds the all-view SH gradient
         color, radii, aux = view_parallel.forward_backward(scene, cam, bg, loss_grad, self.exchange, tanfovx, tanfovy,
                                                            sh_adam=sh_adam if self.world == 1 else None)
         self.exchange.reduce(scene, cam, aux, sh_adam=sh_adam if (self.world > 1 and fused_sh) else None)
         g = self.exchange.shaped()
         m, v = self.state["xyz"]
-        _C.adam_step(self.xyz, g["dL_dmeans3D"], m, v, self.xyz_lr(it), it, grad_scale=scale)
+        _C.adam_step(self.xyz, g["dL_dmeans3D"], m, v, self.xyz_lr(it), steps["xyz"], grad_scale=scale)
         if not fused_sh:
             m, v = self.state["features"]
-            _C.adam_step(self.features, g["dL_dsh"], m, v, o.feature_lr, it, lr_tail=o.feature_lr / 20.0,
-                         period=3 * self.M, head=3, grad_scale=scale)
+            _C.adam_step(self.features, g["dL_dsh"], m, v, o.feature_lr, steps["features"],
+                         lr_tail=o.feature_lr / 20.0, period=3 * self.M, head=3, grad_scale=scale)
         names = ("opacity_raw", "scaling_raw", "rotation_raw")
         densify = None
-        if self.densify_stats:
+        if stats:
             densify = (aux["dL_dmeans2D"], radii, self.xyz_gradient_accum, self.denom, self.max_radii2D)
+        # a held opacity takes a step of size zero (its moments are about to be cleared by the reset that asked for it)
         _C.adam_step_activated(
             tuple(getattr(self, n) for n in names),
             (g["dL_dopacity"], g["dL_dscales"], g["dL_drotations"]),
             tuple(self.state[n][0] for n in names), tuple(self.state[n][1] for n in names),
-            (self.opacities, self.scales, self.rotations), (o.opacity_lr, o.scaling_lr, o.rotation_lr), it,
-            grad_scale=scale, densify=densify)
+            (self.opacities, self.scales, self.rotations),
+            (0.0 if hold_opacity else o.opacity_lr, o.scaling_lr, o.rotation_lr),
+            tuple(max(steps[n], 1) for n in names), grad_scale=scale, densify=densify)
         return terms["loss"], color, radii
+
+    # ---- everything below changes the set of Gaussians: host-side tensor surgery as in the reference ----
+
+    def _add_densification_stats(self, dL_dmeans2D, radii):
+        """train.py:115 and gaussian_model.py:550-552 for an iteration whose optimiser step is skipped."""
+        vis = radii > 0
+        self.max_radii2D[vis] = torch.max(self.max_radii2D[vis], radii[vis])
+        self.xyz_gradient_accum[vis] += torch.norm(dL_dmeans2D[vis, :2], dim=-1, keepdim=True)
+        self.denom[vis] += 1
+
+    _ROWS = ("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw")
+
+    def _append_rows(self, new, new_extras):
+        """gaussian_model.py:444-488: new Gaussians start with zero Adam moments; the statistics restart."""
+        for name in self._ROWS:
+            add = new[name]
+            setattr(self, name, torch.cat((getattr(self, name), add), dim=0).contiguous())
+            m, v = self.state[name]
+            self.state[name] = (torch.cat((m, torch.zeros_like(add)), dim=0).contiguous(),
+                                torch.cat((v, torch.zeros_like(add)), dim=0).contiguous())
+        for name, add in new_extras.items():
+            self.extras[name] = torch.cat((self.extras[name], add), dim=0)
+        self._activate()
+        self._resized()
+
+    def prune_points(self, mask):
+        """Drop the Gaussians where ``mask`` is set, with their Adam moments and statistics (:409-442)."""
+        keep = ~mask
+        for name in self._ROWS:
+            setattr(self, name, getattr(self, name)[keep].contiguous())
+            m, v = self.state[name]
+            self.state[name] = (m[keep].contiguous(), v[keep].contiguous())
+        for name in self.extras:
+            self.extras[name] = self.extras[name][keep]
+        stats = (self.xyz_gradient_accum[keep], self.denom[keep], self.max_radii2D[keep]) if self.densify_stats else None
+        self._activate()
+        self._resized()
+        if stats is not None:
+            self.xyz_gradient_accum, self.denom, self.max_radii2D = (t.contiguous() for t in stats)
+
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        """Small Gaussians with a large view-space gradient are duplicated in place (:517-532)."""
+        sel = torch.norm(grads, dim=-1) >= grad_threshold
+        sel &= self.scales.max(dim=1).values <= self.opt.percent_dense * scene_extent
+        self._append_rows({n: getattr(self, n)[sel] for n in self._ROWS}, {n: t[sel] for n, t in self.extras.items()})
+
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, generator=None):
+        """Large ones are replaced by N samples of themselves, scaled down by 0.8 N (:490-515)."""
+        from .gaussian_model import quaternion_to_rotation
+        padded = torch.zeros(self.P, device=self.xyz.device)
+        padded[:grads.shape[0]] = grads.squeeze(-1)
+        sel = padded >= grad_threshold
+        sel &= self.scales.max(dim=1).values > self.opt.percent_dense * scene_extent
+        scales = torch.exp(self.scaling_raw[sel])
+        stds = scales.repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+        rots = quaternion_to_rotation(self.rotation_raw[sel]).repeat(N, 1, 1)
+        new = dict(
+            xyz=torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.xyz[sel].repeat(N, 1),
+            scaling_raw=torch.log(scales.repeat(N, 1) / (0.8 * N)),
+            rotation_raw=self.rotation_raw[sel].repeat(N, 1),
+            features=self.features[sel].repeat(N, 1, 1),
+            opacity_raw=self.opacity_raw[sel].repeat(N, 1))
+        self._append_rows(new, {n: t[sel].repeat(N, *([1] * (t.dim() - 1))) for n, t in self.extras.items()})
+        added = N * int(sel.sum())
+        self.prune_points(torch.cat((sel, torch.zeros(added, dtype=torch.bool, device=sel.device))))
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """gaussian_model.py:534-548.  With several ranks the statistics are merged first and ``generator`` must be
+        seeded alike everywhere, so that every rank makes the same decisions and draws the same samples."""
+        self.sync_densification_stats()
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        self.densify_and_clone(grads, max_grad, extent)
+        self.densify_and_split(grads, max_grad, extent, generator=generator)
+        prune = (self.opacities < min_opacity).squeeze(-1)
+        if max_screen_size:
+            big_vs = self.max_radii2D > max_screen_size
+            big_ws = self.scales.max(dim=1).values > 0.1 * extent
+            prune = prune | big_vs | big_ws
+        self.prune_points(prune)
+
+    def reset_opacity(self):
+        """Opacities above 0.01 fall back to it; the opacities' Adam moments restart (:331-334, :394-407)."""
+        cap = torch.full_like(self.opacity_raw, 0.01)
+        self.opacity_raw = inverse_sigmoid(torch.min(torch.sigmoid(self.opacity_raw), cap)).contiguous()
+        self.state["opacity_raw"] = (torch.zeros_like(self.opacity_raw), torch.zeros_like(self.opacity_raw))
+        self.opacities = torch.sigmoid(self.opacity_raw)
+
+    def train_iteration(self, cam, gt_image, bg, tanfovx, tanfovy, scene_extent, white_background=False, seed=0):
+        """The whole loop body of train.py:69-128 for iteration ``self.iteration + 1``.
+
+        An iteration that densifies replaces every parameter before the optimiser runs, so none takes a step; one
+        that only resets the opacities steps everything else.  The last iteration takes no step either."""
+        it, o = self.iteration + 1, self.opt
+        if it % 1000 == 0:
+            self.oneupSHdegree()
+        growing = it < o.densify_until_iter
+        densify_now = growing and it > o.densify_from_iter and it % o.densification_interval == 0
+        reset_now = growing and (it % o.opacity_reset_interval == 0 or
+                                 (white_background and it == o.densify_from_iter))
+        out = self.step(cam, gt_image, bg, tanfovx, tanfovy, optimize=not densify_now and it < o.iterations,
+                        hold_opacity=reset_now, collect_stats=growing)
+        if densify_now:
+            gen = torch.Generator(device=self.xyz.device)
+            gen.manual_seed(1_000_003 * seed + it)
+            size_threshold = 20 if it > o.opacity_reset_interval else None
+            self.densify_and_prune(o.densify_grad_threshold, 0.005, scene_extent, size_threshold, generator=gen)
+        if reset_now:
+            self.reset_opacity()
+        return out

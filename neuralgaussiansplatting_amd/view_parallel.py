@@ -55,14 +55,19 @@ def _all_gather_rows(rows, local, group=None):
         dist.all_gather(list(rows.unbind(0)), local, group=group)
 
 
+def _aligned_fields(names, sizes):
+    """Fields laid end to end, each starting on a 16-byte boundary (the kernels that read and write them use
+    four-float accesses); the few padding floats stay zero.  -> ({field: (offset, length)}, total) in floats."""
+    lay, off = {}, 0
+    for name, n in zip(names, sizes):
+        lay[name] = (off, n)
+        off += (n + 3) & ~3
+    return lay, off
+
+
 def bucket_layout(P, M):
     """-> ({field: (offset, length)}, total) in float32 elements."""
-    sizes = (3 * P, 3 * M * P, P, 3 * P, 4 * P)
-    lay, off = {}, 0
-    for name, n in zip(BUCKET_FIELDS, sizes):
-        lay[name] = (off, n)
-        off += n
-    return lay, off
+    return _aligned_fields(BUCKET_FIELDS, (3 * P, 3 * M * P, P, 3 * P, 4 * P))
 
 
 class GradientBucket:
@@ -72,7 +77,7 @@ class GradientBucket:
     def __init__(self, P, M, device):
         self.P, self.M = P, M
         self.layout, total = bucket_layout(P, M)
-        self.flat = torch.empty(total, dtype=torch.float32, device=device)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.views = {k: self.flat[o:o + n] for k, (o, n) in self.layout.items()}
 
     def shaped(self):
@@ -115,13 +120,11 @@ class FactoredGradientExchange:
         if world_size is None:
             world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.world = world_size
-        sizes = (3 * P, P, 3 * P, 4 * P)
-        self.reduced = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-        self.views, off = {}, 0
-        for name, n in zip(REDUCED_FIELDS, sizes):
-            self.views[name] = self.reduced[off:off + n]
-            off += n
-        self.row = 3 * P + 4  # one view's contribution: masked colour gradient [P,3], camera position, one pad
+        lay, total = _aligned_fields(REDUCED_FIELDS, (3 * P, P, 3 * P, 4 * P))
+        self.reduced = torch.zeros(total, dtype=torch.float32, device=device)
+        self.views = {name: self.reduced[off:off + n] for name, (off, n) in lay.items()}
+        # one view's contribution: masked colour gradient [P,3], camera position, padding to whole 16 bytes
+        self.row = ((3 * P + 3) + 3) & ~3
         self.local = torch.zeros(self.row, dtype=torch.float32, device=device)
         self.gathered = torch.zeros((self.world, self.row), dtype=torch.float32, device=device)
         self.dL_dsh = torch.empty((P, M, 3), dtype=torch.float32, device=device)

@@ -270,3 +270,270 @@ def test_two_rank_training_keeps_replicas_identical(exchange, C):
     port = 35500 + os.getpid() % 2000 + (7 if exchange == "dense" else 0)
     mp.spawn(_two_rank_trainer_worker, args=(port, exchange, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ---- densification, pruning, opacity reset -----------------------------------------------------------------------
+
+class _TorchAdamScene:
+    """The same state held the reference's way -- one nn.Parameter per group inside torch.optim.Adam -- with the
+    reference's surgery on it (scene/gaussian_model.py:394-548): rows appended with zero moments, rows dropped with
+    their moments, a replaced tensor whose moments restart.  Built from a trainer so both start from equal bits."""
+    GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+    def __init__(self, tr, percent_dense):
+        cl = lambda t: torch.nn.Parameter(t.detach().clone())
+        vals = dict(xyz=tr.xyz, f_dc=tr.features[:, :1], f_rest=tr.features[:, 1:], opacity=tr.opacity_raw,
+                    scaling=tr.scaling_raw, rotation=tr.rotation_raw)
+        mom = dict(xyz=tr.state["xyz"], opacity=tr.state["opacity_raw"], scaling=tr.state["scaling_raw"],
+                   rotation=tr.state["rotation_raw"],
+                   f_dc=tuple(t[:, :1] for t in tr.state["features"]), f_rest=tuple(t[:, 1:] for t in tr.state["features"]))
+        self.opt = torch.optim.Adam([{"params": [cl(vals[n])], "lr": 0.0, "name": n} for n in self.GROUPS], eps=1e-15)
+        for g in self.opt.param_groups:
+            m, v = mom[g["name"]]
+            self.opt.state[g["params"][0]] = dict(step=torch.tensor(5.0), exp_avg=m.clone().contiguous(),
+                                                  exp_avg_sq=v.clone().contiguous())
+        self.accum, self.denom = tr.xyz_gradient_accum.clone(), tr.denom.clone()
+        self.max_radii = tr.max_radii2D.clone()
+        self.percent_dense = percent_dense
+
+    def p(self, name):
+        return next(g["params"][0] for g in self.opt.param_groups if g["name"] == name)
+
+    def scaling(self):
+        return torch.exp(self.p("scaling"))
+
+    def _swap(self, transform_param, transform_moment):
+        for g in self.opt.param_groups:
+            old = g["params"][0]
+            st = self.opt.state.pop(old)
+            st["exp_avg"], st["exp_avg_sq"] = transform_moment(g["name"], st["exp_avg"]), transform_moment(g["name"], st["exp_avg_sq"])
+            g["params"][0] = torch.nn.Parameter(transform_param(g["name"], old.detach()))
+            self.opt.state[g["params"][0]] = st
+
+    def append(self, new):
+        self._swap(lambda n, t: torch.cat((t, new[n]), dim=0), lambda n, t: torch.cat((t, torch.zeros_like(new[n])), dim=0))
+        n = self.p("xyz").shape[0]
+        self.accum, self.denom = torch.zeros((n, 1), device=DEV), torch.zeros((n, 1), device=DEV)
+        self.max_radii = torch.zeros(n, dtype=torch.int32, device=DEV)
+
+    def prune(self, mask):
+        keep = ~mask
+        self._swap(lambda n, t: t[keep], lambda n, t: t[keep])
+        self.accum, self.denom, self.max_radii = self.accum[keep], self.denom[keep], self.max_radii[keep]
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator):
+        from neuralgaussiansplatting_amd.gaussian_model import quaternion_to_rotation
+        grads = self.accum / self.denom
+        grads[grads.isnan()] = 0.0
+        small = self.scaling().max(dim=1).values <= self.percent_dense * extent
+        sel = (torch.norm(grads, dim=-1) >= max_grad) & small
+        self.append({n: self.p(n).detach()[sel] for n in self.GROUPS})
+        n0 = self.p("xyz").shape[0]
+        padded = torch.zeros(n0, device=DEV)
+        padded[:grads.shape[0]] = grads.squeeze()
+        sel = (padded >= max_grad) & (self.scaling().max(dim=1).values > self.percent_dense * extent)
+        stds = self.scaling().detach()[sel].repeat(2, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+        rots = quaternion_to_rotation(self.p("rotation").detach()[sel]).repeat(2, 1, 1)
+        new = {n: self.p(n).detach()[sel].repeat(2, *([1] * (self.p(n).dim() - 1))) for n in self.GROUPS}
+        new["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + new["xyz"]
+        new["scaling"] = torch.log(stds / (0.8 * 2))
+        self.append(new)
+        self.prune(torch.cat((sel, torch.zeros(2 * int(sel.sum()), dtype=torch.bool, device=DEV))))
+        mask = (torch.sigmoid(self.p("opacity").detach()) < min_opacity).squeeze()
+        if max_screen_size:
+            mask = mask | (self.max_radii > max_screen_size) | (self.scaling().detach().max(dim=1).values > 0.1 * extent)
+        self.prune(mask)
+
+
+def _small_trainer(P=3000, seed=21, log_scale=(-4.2, -2.6)):
+    sc = synthetic.make_scene(P, 3, log_scale, (1.3, 1.3, 1.3), seed=seed, sh_coeffs=16)
+    return train_step.GaussianTrainer(sc, DEV)
+
+
+@pytest.mark.parametrize("max_screen_size", [None, 20])
+def test_densify_and_prune_matches_optimizer_surgery(C, max_screen_size):
+    """From one given state (parameters, Adam moments, statistics) the trainer's clone / split / prune must leave
+    exactly what the reference's operations on torch.optim.Adam leave: same rows in the same order, same moments."""
+    tr = _small_trainer()
+    P = tr.P
+    gen = torch.Generator().manual_seed(77)
+    for name in tr.state:
+        m, v = tr.state[name]
+        m.copy_(torch.randn(m.shape, generator=gen) * 1e-3)
+        v.copy_(torch.rand(v.shape, generator=gen) * 1e-5)
+    tr.denom.copy_(torch.randint(0, 4, (P, 1), generator=gen).float())  # zeros give 0/0 -> NaN -> 0
+    tr.xyz_gradient_accum.copy_(torch.rand(P, 1, generator=gen) * 1e-3 * tr.denom.cpu())
+    tr.opacity_raw[::17] = -6.0  # sigmoid < 0.005: pruned
+    tr._activate()
+    extent = 2.0
+    ref = _TorchAdamScene(tr, tr.opt.percent_dense)
+    tr.max_radii2D.copy_(torch.randint(0, 40, (P,), generator=gen).int())  # cleared by the clone step on both sides
+    ref.max_radii = tr.max_radii2D.clone()
+    tr.extras["normals"] = torch.arange(P, device=DEV).float().reshape(P, 1).repeat(1, 3)
+    g1 = torch.Generator(device=DEV).manual_seed(5)
+    g2 = torch.Generator(device=DEV).manual_seed(5)
+    tr.densify_and_prune(0.0002, 0.005, extent, max_screen_size, generator=g1)
+    ref.densify_and_prune(0.0002, 0.005, extent, max_screen_size, generator=g2)
+    assert tr.P == ref.p("xyz").shape[0] and tr.P != P
+    want = dict(xyz=ref.p("xyz"), features=torch.cat((ref.p("f_dc"), ref.p("f_rest")), dim=1), opacity_raw=ref.p("opacity"),
+                scaling_raw=ref.p("scaling"), rotation_raw=ref.p("rotation"))
+    for name, w in want.items():
+        assert torch.equal(getattr(tr, name), w.detach()), name
+    st = lambda n, k: ref.opt.state[ref.p(n)][k]
+    for k, i in (("exp_avg", 0), ("exp_avg_sq", 1)):
+        assert torch.equal(tr.state["xyz"][i], st("xyz", k))
+        assert torch.equal(tr.state["features"][i], torch.cat((st("f_dc", k), st("f_rest", k)), dim=1))
+        assert torch.equal(tr.state["opacity_raw"][i], st("opacity", k))
+        assert torch.equal(tr.state["scaling_raw"][i], st("scaling", k))
+        assert torch.equal(tr.state["rotation_raw"][i], st("rotation", k))
+    assert torch.equal(tr.xyz_gradient_accum, ref.accum) and torch.equal(tr.denom, ref.denom)
+    assert torch.equal(tr.max_radii2D, ref.max_radii)
+    # activated copies, gradient buffers and extra rows follow the new size
+    assert torch.equal(tr.scales, torch.exp(tr.scaling_raw)) and tr.opacities.shape == (tr.P, 1)
+    assert tr.exchange.P == tr.P and tr.extras["normals"].shape == (tr.P, 3)
+    # a split Gaussian's two children carry their parent's extra row; clones too
+    assert int(tr.extras["normals"][:, 0].unique().numel()) < tr.P
+    # and the resized trainer keeps training
+    cam = make_camera(96, 64, synthetic.FOVX, (0.7, 0.5, -4.0), device=DEV)
+    gt = torch.rand(3, 64, 96, generator=gen).to(DEV)
+    tr.step(cam, gt, torch.zeros(3, device=DEV), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5))
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(t).all() for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw))
+
+
+def test_reset_opacity_caps_and_restarts_moments(C):
+    tr = _small_trainer(500)
+    tr.state["opacity_raw"][0].fill_(0.3)
+    before = tr.opacities.clone()
+    tr.reset_opacity()
+    assert float(tr.opacities.max()) <= 0.01 + 1e-7
+    low = before < 0.01
+    assert torch.allclose(tr.opacities[low], before[low], atol=1e-7)
+    assert float(tr.state["opacity_raw"][0].abs().max()) == 0.0 and float(tr.state["opacity_raw"][1].abs().max()) == 0.0
+    assert torch.allclose(torch.sigmoid(tr.opacity_raw), tr.opacities)
+
+
+def test_schedule_skips_the_steps_torch_adam_skips(C):
+    """train_iteration on a compressed schedule, beside a torch.optim.Adam whose parameters are replaced at the
+    points where the reference replaces them (train.py:113-128: densification replaces all, the opacity reset the
+    opacities; a replaced parameter has no gradient when the optimiser runs, so its step count stands still)."""
+    tr = _small_trainer(2500, seed=4, log_scale=(-3.9, -2.9))
+    o = train_step.OptimizationParams()
+    o.iterations, o.densify_from_iter, o.densification_interval = 14, 2, 3
+    o.opacity_reset_interval, o.densify_until_iter = 6, 11
+    tr.opt = o
+    names = ("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw")
+    dummy = {n: torch.nn.Parameter(torch.zeros(1)) for n in names}
+    opt = torch.optim.Adam([{"params": [dummy[n]], "name": n} for n in names], lr=0.0)
+
+    def replace(group_names):
+        for g in opt.param_groups:
+            if g["name"] in group_names:
+                st = opt.state.pop(g["params"][0], None)
+                g["params"][0] = torch.nn.Parameter(torch.zeros(1))
+                if st is not None:
+                    opt.state[g["params"][0]] = st
+
+    cam = make_camera(96, 64, synthetic.FOVX, (0.7, 0.5, -4.0), device=DEV)
+    gt = torch.rand(3, 64, 96, generator=torch.Generator().manual_seed(2)).to(DEV)
+    bg = torch.ones(3, device=DEV)
+    sizes, degree0 = [tr.P], tr.sh_degree
+    for it in range(1, o.iterations + 1):
+        for g in opt.param_groups:
+            g["params"][0].grad = torch.ones(1)
+        if it < o.densify_until_iter:
+            if it > o.densify_from_iter and it % o.densification_interval == 0:
+                replace(names)
+            if it % o.opacity_reset_interval == 0 or it == o.densify_from_iter:  # white background
+                replace(("opacity_raw",))
+        if it < o.iterations:
+            opt.step()
+        opt.zero_grad(set_to_none=True)
+        tr.train_iteration(cam, gt, bg, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), scene_extent=2.0,
+                           white_background=True)
+        sizes.append(tr.P)
+        want = {g["name"]: int(opt.state[g["params"][0]]["step"]) if opt.state.get(g["params"][0]) else 0
+                for g in opt.param_groups}
+        assert tr.adam_steps == want, (it, tr.adam_steps, want)
+    torch.cuda.synchronize()
+    assert tr.iteration == o.iterations and tr.sh_degree == degree0
+    assert len(set(sizes)) > 1  # the set of Gaussians did change
+    assert tr.adam_steps["opacity_raw"] == tr.adam_steps["xyz"] - 1
+    assert all(torch.isfinite(t).all() for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw))
+    tr.sh_degree = 1
+    tr.oneupSHdegree(); tr.oneupSHdegree(); tr.oneupSHdegree()
+    assert tr.sh_degree == 3 == tr.max_sh_degree
+
+
+def test_activated_adam_takes_a_step_count_per_group(C):
+    gen = torch.Generator().manual_seed(9)
+    P = 300
+    raw0 = [torch.randn(P, w, generator=gen) for w in (1, 3, 4)]
+    grads = [torch.randn(P, w, generator=gen) for w in (1, 3, 4)]
+    mom = [(torch.randn(P, w, generator=gen) * 0.01, torch.rand(P, w, generator=gen) * 1e-4) for w in (1, 3, 4)]
+    lrs, steps = (0.05, 0.005, 0.001), (3, 40, 41)
+
+    def run(step_arg, only=None):
+        raw = [r.clone().to(DEV) for r in raw0]
+        m, v = [a.clone().to(DEV) for a, _ in mom], [b.clone().to(DEV) for _, b in mom]
+        act = [torch.empty_like(r) for r in raw]
+        C.adam_step_activated(raw, [g.to(DEV) for g in grads], m, v, act, lrs, step_arg)
+        return raw
+    mixed = run(steps)
+    for i, t in enumerate(steps):
+        assert torch.equal(mixed[i], run(t)[i])
+    assert not torch.equal(mixed[0], run(steps[1])[0])
+    with pytest.raises(RuntimeError):
+        run((1, 0, 1))
+
+
+def _two_rank_densify_worker(rank, port, ret):
+    """Two gloo ranks sharing the one GPU run the full loop body on a compressed schedule, each on its own view:
+    the merged statistics and the identically seeded sampler must lead both to the same new set of Gaussians."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        P, W, H, D = 2501, 96, 64, 3  # an odd count: gradient buffers must cope with any size
+        sc = synthetic.make_scene(P, D, (-3.9, -2.9), (1.3, 1.3, 1.3), seed=4, sh_coeffs=16)
+        cam = make_camera(W, H, synthetic.FOVX, ((0.7, 0.5, -4.0), (-1.8, 0.4, -3.5))[rank], device=DEV)
+        gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(60 + rank)).to(DEV)
+        bg = torch.zeros(3, device=DEV)
+        tr = train_step.GaussianTrainer(sc, DEV)
+        o = train_step.OptimizationParams()
+        o.iterations, o.densify_from_iter, o.densification_interval = 9, 1, 3
+        o.opacity_reset_interval, o.densify_until_iter = 6, 8
+        tr.opt = o
+        sizes = [tr.P]
+        for _ in range(o.iterations):
+            tr.train_iteration(cam, gt, bg, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), scene_extent=2.0, seed=3)
+            sizes.append(tr.P)
+        torch.cuda.synchronize()
+        state = [t.detach().cpu() for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw)]
+        flat = torch.cat([t.reshape(-1).double() for t in state] + [torch.tensor(sizes).double()])
+        n = torch.tensor([flat.numel()])
+        counts = [torch.zeros_like(n) for _ in range(2)]
+        dist.all_gather(counts, n)
+        same_size = int(counts[0]) == int(counts[1])
+        equal = False
+        if same_size:
+            both = [torch.empty_like(flat) for _ in range(2)]
+            dist.all_gather(both, flat)
+            equal = torch.equal(both[0], both[1])
+        ret[rank] = bool(same_size and equal and torch.isfinite(flat).all() and len(set(sizes)) > 1)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_densification_keeps_replicas_identical(C):
+    import os
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 37700 + os.getpid() % 2000
+    mp.spawn(_two_rank_densify_worker, args=(port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}

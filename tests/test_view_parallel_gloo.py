@@ -97,7 +97,8 @@ def _factored_worker(rank, world, port, P, M, D, ret):
         sh = ex.shaped()
         ok = ok and torch.equal(sh["dL_dsh"], want_sh) and sh["dL_dsh"].shape == (P, M, 3)
         ok = ok and sh["dL_dopacity"].shape == (P, 1) and set(sh) == set(view_parallel.BUCKET_FIELDS)
-        ok = ok and ex.bytes_sent_per_rank() == 4 * (3 * P + 4 + 11 * P)
+        up4 = lambda n: (n + 3) & ~3  # fields start on 16-byte boundaries
+        ok = ok and ex.bytes_sent_per_rank() == 4 * (up4(3 * P + 3) + up4(3 * P) + up4(P) + up4(3 * P) + 4 * P)
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -155,6 +156,9 @@ def test_bucket_layout_and_sharding():
     lay, total = view_parallel.bucket_layout(100, 16)
     assert total == 100 * 59  # 3 + 48 + 1 + 3 + 4 floats per Gaussian
     assert [lay[k][0] for k in view_parallel.BUCKET_FIELDS] == [0, 300, 5100, 5200, 5500]
+    lay, total = view_parallel.bucket_layout(7, 16)  # every field starts on a 16-byte boundary whatever the count
+    assert [lay[k] for k in view_parallel.BUCKET_FIELDS] == [(0, 21), (24, 336), (360, 7), (368, 21), (392, 28)]
+    assert total == 420
     assert view_parallel.shard_views(8, 1, 4) == [1, 5]
     assert sorted(sum((view_parallel.shard_views(10, r, 3) for r in range(3)), [])) == list(range(10))
     b = view_parallel.GradientBucket(5, 1, torch.device("cpu"))
