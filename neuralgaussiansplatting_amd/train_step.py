@@ -103,6 +103,42 @@ class GaussianTrainer:
         self._dL_dpix = None
         self._resized()
 
+    @classmethod
+    def from_model(cls, model, device, **kw):
+        """Take over a ``GaussianModel``'s raw parameters (fresh from ``create_from_pcd`` or ``load_ply``), the way
+        ``training_setup`` hands them to the optimiser (gaussian_model.py:252-283).  Normals and the per-Gaussian
+        feature vectors ride along in ``extras``."""
+        from .synthetic import Scene
+        with torch.no_grad():
+            scene = Scene(model.get_xyz, model.get_features, model.get_opacity, model.get_scaling, model.get_rotation,
+                          model.active_sh_degree)
+            tr = cls(scene, device, spatial_lr_scale=model.spatial_lr_scale, **kw)
+            f = lambda t: t.detach().to(tr.xyz.device, torch.float32).contiguous().clone()
+            tr.opacity_raw, tr.scaling_raw, tr.rotation_raw = f(model._opacity), f(model._scaling), f(model._rotation)
+            tr._activate()
+            tr.max_sh_degree = model.max_sh_degree
+            tr.extras = dict(normals=f(model._normals), features64=f(model._features))
+        return tr
+
+    def to_model(self):
+        """The current parameters as a ``GaussianModel`` (for ``save_ply`` or ``render()``)."""
+        from torch import nn
+        from .gaussian_model import GaussianModel
+        m = GaussianModel(self.max_sh_degree)
+        m.active_sh_degree = self.sh_degree
+        m.spatial_lr_scale = self.spatial_lr_scale
+        mk = lambda t: nn.Parameter(t.detach().clone().contiguous().requires_grad_(True))
+        m._xyz, m._opacity, m._scaling, m._rotation = mk(self.xyz), mk(self.opacity_raw), mk(self.scaling_raw), \
+            mk(self.rotation_raw)
+        m._features_dc, m._features_rest = mk(self.features[:, :1]), mk(self.features[:, 1:])
+        zeros = lambda w: torch.zeros((self.P, w), device=self.xyz.device)
+        m._normals = mk(self.extras.get("normals", zeros(3)))
+        from .gaussian_model import NUM_FEATURES
+        m._features = mk(self.extras.get("features64", zeros(NUM_FEATURES)))
+        if self.densify_stats:
+            m.max_radii2D = self.max_radii2D.float()
+        return m
+
     def _resized(self):
         """(Re)build everything whose size follows the number of Gaussians: gradient buffers, statistics."""
         dev = self.xyz.device

@@ -537,3 +537,36 @@ def test_two_rank_densification_keeps_replicas_identical(C):
     port = 37700 + os.getpid() % 2000
     mp.spawn(_two_rank_densify_worker, args=(port, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_point_cloud_to_trained_ply(C, tmp_path):
+    """The two ends around the trainer: a point cloud initialises a model (nearest-neighbour scales), the trainer
+    takes it over, trains with densification on a compressed schedule, and the result is saved and read back."""
+    from neuralgaussiansplatting_amd.gaussian_model import GaussianModel
+    from neuralgaussiansplatting_amd.ply_io import BasicPointCloud
+    gen = np.random.default_rng(3)
+    n = 1500
+    pts = (gen.random((n, 3)) * 2.0 - 1.0).astype(np.float32)
+    pcd = BasicPointCloud(points=pts, colors=gen.random((n, 3)).astype(np.float32), normals=np.zeros((n, 3), np.float32))
+    model = GaussianModel(3).create_from_pcd(pcd, spatial_lr_scale=2.0, device=DEV)
+    tr = train_step.GaussianTrainer.from_model(model, DEV)
+    assert tr.M == 16 and tr.sh_degree == 0 and tr.max_sh_degree == 3 and tr.spatial_lr_scale == 2.0
+    assert torch.equal(tr.scaling_raw, model._scaling.detach()) and torch.equal(tr.opacity_raw, model._opacity.detach())
+    o = train_step.OptimizationParams()
+    o.iterations, o.densify_from_iter, o.densification_interval = 12, 2, 4
+    o.opacity_reset_interval, o.densify_until_iter = 8, 11
+    o.densify_grad_threshold = 1e-6  # a dozen iterations gather little gradient
+    tr.opt = o
+    cam = make_camera(96, 64, synthetic.FOVX, (0.7, 0.5, -4.0), device=DEV)
+    gt = torch.rand(3, 64, 96, generator=torch.Generator().manual_seed(2)).to(DEV)
+    for _ in range(o.iterations):
+        tr.train_iteration(cam, gt, torch.zeros(3, device=DEV), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                           scene_extent=2.0)
+    assert tr.P != n and tr.extras["features64"].shape == (tr.P, 64)
+    out = tr.to_model()
+    path = str(tmp_path / "point_cloud" / "iteration_12" / "point_cloud.ply")
+    out.save_ply(path)
+    back = GaussianModel(3).load_ply(path, device=DEV)
+    for a, b in zip(out.parameters(), back.parameters()):
+        assert torch.equal(a.detach(), b.detach())
+    assert back._xyz.shape == (tr.P, 3) and torch.isfinite(back._xyz).all()
