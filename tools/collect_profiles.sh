@@ -14,6 +14,8 @@ done
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29671 \
     bench.py --gpus 2 --steps 5 --warmup 1 --backend gloo --no-idxmap 2> $OUT/gloo2.err | grep '"metric"' > $OUT/c4_gloo2_rehearsal.json
 echo "gloo rehearsal done"
+timeout -k 10 300 python3 tools/train_demo.py --iterations 7000 --gt 150000 --init 30000 --views 100 --out $OUT/train_demo.json > /dev/null 2> $OUT/train_demo.err
+echo "training run done"
 cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1

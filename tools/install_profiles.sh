@@ -6,6 +6,7 @@ TAG=${1:-r01}
 SRC=gpurun_out/final
 for c in c1 c2 c3 c4 c5; do cp $SRC/${c}_bench.json profiles/${TAG}_${c}_bench.json; done
 cp $SRC/c4_gloo2_rehearsal.json profiles/${TAG}_c4_gloo2_rehearsal.json
+cp $SRC/train_demo.json profiles/${TAG}_train_demo.json
 cp $SRC/trace/*/*_kernel_stats.csv profiles/${TAG}_c4_final_kernel_stats.csv
 python3 tools/kernel_stats_md.py profiles/${TAG}_c4_final_kernel_stats.csv "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline" > profiles/${TAG}_c4_final_kernel_stats.md
 python3 tools/pmc_summary.py --fetch $SRC/pmc_fetch --write $SRC/pmc_write --config c4 --fwd-runs 5 --bwd-runs 4 \
