@@ -41,6 +41,44 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, const float* __restrict__ s
     return make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
 }
 
+// The same sum taken in two parts, coefficients 0..7 then 8..15 of a degree-3 row, so that a caller can hold half a
+// row at a time; the additions happen in the order above.
+__device__ __forceinline__ float3 sh_to_rgb_first8(const float3* c, float3 dir)
+{
+    const float x = dir.x, y = dir.y, z = dir.z;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    float3 res = f3_scale(NGS_SH_C0, c[0]);
+    res = f3_sub(f3_add(f3_sub(res, f3_scale(NGS_SH_C1 * y, c[1])), f3_scale(NGS_SH_C1 * z, c[2])),
+                 f3_scale(NGS_SH_C1 * x, c[3]));
+    res = f3_add(res, f3_scale(NGS_SH_C2_0 * xy, c[4]));
+    res = f3_add(res, f3_scale(NGS_SH_C2_1 * yz, c[5]));
+    res = f3_add(res, f3_scale(NGS_SH_C2_2 * (2.0f * zz - xx - yy), c[6]));
+    res = f3_add(res, f3_scale(NGS_SH_C2_3 * xz, c[7]));
+    return res;
+}
+__device__ __forceinline__ float3 sh_to_rgb_last8(float3 res, const float3* c8, float3 dir, uint32_t& clamp_bits)
+{
+    const float x = dir.x, y = dir.y, z = dir.z;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y;
+    res = f3_add(res, f3_scale(NGS_SH_C2_4 * (xx - yy), c8[0]));
+    res = f3_add(res, f3_scale(NGS_SH_C3_0 * y * (3.0f * xx - yy), c8[1]));
+    res = f3_add(res, f3_scale(NGS_SH_C3_1 * xy * z, c8[2]));
+    res = f3_add(res, f3_scale(NGS_SH_C3_2 * y * (4.0f * zz - xx - yy), c8[3]));
+    res = f3_add(res, f3_scale(NGS_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), c8[4]));
+    res = f3_add(res, f3_scale(NGS_SH_C3_4 * x * (4.0f * zz - xx - yy), c8[5]));
+    res = f3_add(res, f3_scale(NGS_SH_C3_5 * z * (xx - yy), c8[6]));
+    res = f3_add(res, f3_scale(NGS_SH_C3_6 * x * (xx - 3.0f * yy), c8[7]));
+    res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+    clamp_bits = (res.x < 0 ? 1u : 0u) | (res.y < 0 ? 2u : 0u) | (res.z < 0 ? 4u : 0u);
+    return make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
+}
+
+// LDS staging of the EAGER kernel: a wave holds HALF of its 64 SH rows at a time, as six slots of 64 float4 (slot c of
+// row g at float4 index c * SH_SLOT + g; the odd slot stride keeps both the row-major writes and the lane-major reads
+// free of bank conflicts).  6.1 KiB per wave instead of 13: LDS no longer caps the waves per SIMD.
+#define SH_SLOT 65
+#define SH_WAVE_F4 (6 * SH_SLOT)
+
 // EAGER: the common training shape (scales + rotations, full SH rows of 16 coefficients at degree 3).  All of a
 // Gaussian's inputs are requested before any arithmetic: the culling tests that decide whether they are needed
 // depend on one another (position -> covariance -> footprint -> colour), and waiting for each answer before asking
@@ -55,35 +93,47 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     uint32_t* __restrict__ block_sums, uint32_t* __restrict__ misc)
 {
     __shared__ uint32_t wave_tot[NGS_GAUSS_BLOCK / 64];
-    __shared__ float s_sh[EAGER ? NGS_GAUSS_BLOCK * 52 : 1];
+    __shared__ float4 s_sh[EAGER ? (NGS_GAUSS_BLOCK / 64) * SH_WAVE_F4 : 1];
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
     uint32_t my_tiles = 0;
     int my_radius = 0;
+    float4 ld[EAGER ? 12 : 1];  // this lane's share of the wave's SH rows on their way to LDS
+    float4* const wslots = s_sh + (EAGER ? (threadIdx.x >> 6) * SH_WAVE_F4 : 0);
     if (EAGER) {
-        // Each wave moves its 64 SH rows (12 KiB, contiguous in memory) into LDS with coalesced streaming loads:
+        // Each wave moves its 64 SH rows (12 KiB, contiguous in memory) through LDS with coalesced streaming loads:
         // a lane reading its own 192-byte row would make every load instruction touch 64 different cache lines.
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int wave_first = blockIdx.x * NGS_GAUSS_BLOCK + wave * 64;
-        float* const wrows = s_sh + wave * 64 * 52;
+        // All twelve loads are issued here; the first half of every row goes to LDS now, the second half waits in
+        // registers until the first has been consumed.  Rows are written and read by the same wave only: no
+        // workgroup barrier is needed, LDS operations of a wave complete in order.
+        const int lane = threadIdx.x & 63;
+        const int wave_first = blockIdx.x * NGS_GAUSS_BLOCK + (threadIdx.x >> 6) * 64;
 #pragma unroll
         for (int t = 0; t < 12; t++) {
             const int f = t * 64 + lane, g = f / 12, c = f - g * 12;
-            if (wave_first + g < P) *(float4*)(wrows + g * 52 + c * 4) = stream_load4(shs + (size_t)(wave_first + g) * 48 + 4 * c);
+            ld[t] = make_float4(0, 0, 0, 0);
+            if (wave_first + g < P) ld[t] = stream_load4(shs + (size_t)(wave_first + g) * 48 + 4 * c);
         }
-        // rows are written and read by the same wave only: no workgroup barrier needed, LDS operations of a wave
-        // complete in order
+#pragma unroll
+        for (int t = 0; t < 12; t++) {
+            const int f = t * 64 + lane, g = f / 12, c = f - g * 12;
+            if (c < 6) wslots[c * SH_SLOT + g] = ld[t];
+        }
     }
+    // Geometry first (projection, footprint, tile rectangle); `live` = the Gaussian produces instances.
+    bool live = false;
+    float px = 0, py = 0, pz = 0, e_op = 0, view_z = 0, ix = 0, iy = 0, con_x = 0, con_y = 0, con_z = 0;
+    uint32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
     if (idx < P) {
-        const float px = means[3 * idx], py = means[3 * idx + 1], pz = means[3 * idx + 2];
-        float4 e_sh[EAGER ? 12 : 1];
+        px = means[3 * idx]; py = means[3 * idx + 1]; pz = means[3 * idx + 2];
         float4 e_q = make_float4(0, 0, 0, 0);
-        float e_s0 = 0, e_s1 = 0, e_s2 = 0, e_op = 0;
+        float e_s0 = 0, e_s1 = 0, e_s2 = 0;
         if (EAGER) {
             e_q = ((const float4*)rots)[idx];
             e_s0 = scales[3 * idx]; e_s1 = scales[3 * idx + 1]; e_s2 = scales[3 * idx + 2];
             e_op = opac[idx];
         }
         const float3 pv = xform43(px, py, pz, view);
+        view_z = pv.z;
         if (pv.z <= 0.2f) {
             // The reference aborts the kernel here when `prefiltered` is set
             // (auxiliary.h:156-160); this library raises an error flag that the
@@ -112,64 +162,88 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
                 const float l1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
                 const float l2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
                 const float rad = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
-                const float ix = ndc_to_pix(projx, cam.W), iy = ndc_to_pix(projy, cam.H);
+                ix = ndc_to_pix(projx, cam.W); iy = ndc_to_pix(projy, cam.H);
                 const int ri = (int)rad;  // v_cvt_i32_f32 saturates like the reference's conversion
                 int a;
-                a = max(0, (int)((ix - ri) / NGS_TILE_W)); const uint32_t x0 = min((uint32_t)cam.grid_x, (uint32_t)a);
-                a = max(0, (int)((iy - ri) / NGS_TILE_H)); const uint32_t y0 = min((uint32_t)cam.grid_y, (uint32_t)a);
-                a = max(0, (int)((ix + ri + NGS_TILE_W - 1) / NGS_TILE_W)); const uint32_t x1 = min((uint32_t)cam.grid_x, (uint32_t)a);
-                a = max(0, (int)((iy + ri + NGS_TILE_H - 1) / NGS_TILE_H)); const uint32_t y1 = min((uint32_t)cam.grid_y, (uint32_t)a);
+                a = max(0, (int)((ix - ri) / NGS_TILE_W)); x0 = min((uint32_t)cam.grid_x, (uint32_t)a);
+                a = max(0, (int)((iy - ri) / NGS_TILE_H)); y0 = min((uint32_t)cam.grid_y, (uint32_t)a);
+                a = max(0, (int)((ix + ri + NGS_TILE_W - 1) / NGS_TILE_W)); x1 = min((uint32_t)cam.grid_x, (uint32_t)a);
+                a = max(0, (int)((iy + ri + NGS_TILE_H - 1) / NGS_TILE_H)); y1 = min((uint32_t)cam.grid_y, (uint32_t)a);
                 const uint32_t area = (x1 - x0) * (y1 - y0);
                 if (area != 0) {
-                    float3 col;
-                    uint32_t cb = 0;
-                    if (EAGER) {
-                        float3 d = make_float3(px - campos[0], py - campos[1], pz - campos[2]);
-                        const float len = sqrtf(f3_dot(d, d));
-                        d = make_float3(d.x / len, d.y / len, d.z / len);
-                        const float* my_row = s_sh + (threadIdx.x >> 6) * 64 * 52 + (threadIdx.x & 63) * 52;
-#pragma unroll
-                        for (int k = 0; k < 12; k++) e_sh[k] = *(const float4*)(my_row + 4 * k);
-                        col = sh_to_rgb(3, (const float*)e_sh, d, cb);
-                    } else if (col_pre) {
-                        col = make_float3(col_pre[3 * (size_t)idx], col_pre[3 * (size_t)idx + 1],
-                                          col_pre[3 * (size_t)idx + 2]);
-                    } else {
-                        float3 d = make_float3(px - campos[0], py - campos[1], pz - campos[2]);
-                        const float len = sqrtf(f3_dot(d, d));
-                        d = make_float3(d.x / len, d.y / len, d.z / len);
-                        col = sh_to_rgb(D, shs + (size_t)3 * M * idx, d, cb);
-                    }
-                    // EAGER: the record is parked in this lane's (now consumed) LDS row and leaves with the wave's
-                    // other records as coalesced 1-KiB stores below
-                    float4* r = EAGER ? (float4*)(s_sh + (threadIdx.x >> 6) * 64 * 52 + (threadIdx.x & 63) * 52)
-                                      : rec + 4 * (size_t)idx;
-                    r[0] = make_float4(ix, iy, k.c * dinv, -k.b * dinv);
-                    r[1] = make_float4(k.a * dinv, EAGER ? e_op : opac[idx], col.x, col.y);
-                    r[2] = make_float4(col.z, 0.0f, 0.0f, 0.0f);
-                    if (EAGER) r[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    depth[idx] = pv.z;
-                    rect[idx] = make_uint2(x0 | (x1 << 16), y0 | (y1 << 16));
-                    clamped[idx] = (uint8_t)cb;
+                    live = true;
+                    con_x = k.c * dinv; con_y = -k.b * dinv; con_z = k.a * dinv;
                     my_radius = ri;
                     my_tiles = area;
                 }
             }
         }
+    }
+    // Colour, then the record.
+    float3 col = make_float3(0, 0, 0);
+    uint32_t cb = 0;
+    if (EAGER) {
+        const int lane = threadIdx.x & 63;
+        float3 d = make_float3(px - campos[0], py - campos[1], pz - campos[2]);
+        const float len = sqrtf(f3_dot(d, d));
+        d = make_float3(d.x / len, d.y / len, d.z / len);
+        float4 e_sh[6];
+        float3 part = make_float3(0, 0, 0);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) e_sh[k] = wslots[k * SH_SLOT + lane];
+            part = sh_to_rgb_first8((const float3*)e_sh, d);
+        }
+        // second half of every row: stored by the whole wave, whichever of its lanes are live
+#pragma unroll
+        for (int t = 0; t < 12; t++) {
+            const int f = t * 64 + lane, g = f / 12, c = f - g * 12;
+            if (c >= 6) wslots[(c - 6) * SH_SLOT + g] = ld[t];
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) e_sh[k] = wslots[k * SH_SLOT + lane];
+            col = sh_to_rgb_last8(part, (const float3*)e_sh, d, cb);
+            // the record is parked in this lane's (now consumed) LDS slots and leaves with the wave's other records
+            // as coalesced 1-KiB stores below
+            wslots[0 * SH_SLOT + lane] = make_float4(ix, iy, con_x, con_y);
+            wslots[1 * SH_SLOT + lane] = make_float4(con_z, e_op, col.x, col.y);
+            wslots[2 * SH_SLOT + lane] = make_float4(col.z, 0.0f, 0.0f, 0.0f);
+            wslots[3 * SH_SLOT + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    } else if (live) {
+        if (col_pre) {
+            col = make_float3(col_pre[3 * (size_t)idx], col_pre[3 * (size_t)idx + 1], col_pre[3 * (size_t)idx + 2]);
+        } else {
+            float3 d = make_float3(px - campos[0], py - campos[1], pz - campos[2]);
+            const float len = sqrtf(f3_dot(d, d));
+            d = make_float3(d.x / len, d.y / len, d.z / len);
+            col = sh_to_rgb(D, shs + (size_t)3 * M * idx, d, cb);
+        }
+        float4* r = rec + 4 * (size_t)idx;
+        r[0] = make_float4(ix, iy, con_x, con_y);
+        r[1] = make_float4(con_z, opac[idx], col.x, col.y);
+        r[2] = make_float4(col.z, 0.0f, 0.0f, 0.0f);
+    }
+    if (live) {
+        depth[idx] = view_z;
+        rect[idx] = make_uint2(x0 | (x1 << 16), y0 | (y1 << 16));
+        clamped[idx] = (uint8_t)cb;
+    }
+    if (idx < P) {
         radii[idx] = my_radius;
         tiles[idx] = my_tiles;
     }
     if (EAGER) {
         // records of the wave's visible Gaussians: 4 KiB contiguous per wave (a culled Gaussian's record is never
         // read, so its slot is simply skipped)
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int wave_first = blockIdx.x * NGS_GAUSS_BLOCK + wave * 64;
-        const float* const wrows = s_sh + wave * 64 * 52;
+        const int lane = threadIdx.x & 63;
+        const int wave_first = blockIdx.x * NGS_GAUSS_BLOCK + (threadIdx.x >> 6) * 64;
         const unsigned long long vis = __ballot(my_tiles != 0);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int f = t * 64 + lane, g = f >> 2, c = f & 3;
-            if ((vis >> g) & 1ull) rec[4 * (size_t)(wave_first + g) + c] = *(const float4*)(wrows + g * 52 + c * 4);
+            if ((vis >> g) & 1ull) rec[4 * (size_t)(wave_first + g) + c] = wslots[c * SH_SLOT + g];
         }
     }
     // Tiles touched by this block of 256 Gaussians: the first level of the instance-offset scan.
