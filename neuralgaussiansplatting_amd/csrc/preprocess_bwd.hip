@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
                         stream_load4(shs + (size_t)(wave_first + g) * SH_ROW + 4 * c);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // rows are wave-private and a wave's LDS operations complete in order
     }
 
     if (in_range && !vis) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
     }
 
     if (SH_LDS && adam.param) {
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // rows are wave-private and a wave's LDS operations complete in order
         // Fused optimiser step: the gradient rows never leave the chip.  Each 16-byte group of the wave's 64 rows
         // takes its gradient from LDS (zero for a culled Gaussian, whose moments still decay), its coefficient
         // and Adam moments from memory, and writes all three back; coalesced and streamed like the gradient
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
             }
         }
     } else if (SH_LDS && dL_dsh) {
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // rows are wave-private and a wave's LDS operations complete in order
         // the wave's 64 gradient rows leave as 12 fully coalesced 1-KiB stores; culled Gaussians get zeros
 #pragma unroll
         for (int t = 0; t < SH_ROW * 64 / 4 / 64; t++) {

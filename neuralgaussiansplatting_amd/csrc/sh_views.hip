@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void sh_from_views_kernel(
         float3* const row = (float3*)(wrows + lane * SH_ROW_LDS);
 #pragma unroll
         for (int k = 0; k < 16; k++) row[k] = acc[k];
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // rows are wave-private and a wave's LDS operations complete in order
         const int wave_first = blockIdx.x * NGS_GAUSS_BLOCK + wave * 64;
 #pragma unroll
         for (int t = 0; t < SH_ROW * 64 / 4 / 64; t++) {
