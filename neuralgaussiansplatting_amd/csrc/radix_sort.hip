@@ -401,8 +401,11 @@ void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint32_t* const keys[2]
     if (R <= 0) return;
     const int nblocks = (int)((R + STILE - 1) / STILE);
     int cur = ngs_sort_input_buffer(bits);
-    for (int shift = 0; shift < bits; shift += 8) {
-        const int width = bits - shift < 8 ? bits - shift : 8;
+    // the bits are spread evenly over the passes (13 bits: 7 + 6, not 8 + 5): fewer buckets in a pass mean longer
+    // runs per bucket in the scatter, i.e. fewer partially written memory lines
+    int passes_left = tile_passes(bits);
+    for (int shift = 0, width; shift < bits; shift += width, passes_left--) {
+        width = (bits - shift + passes_left - 1) / passes_left;
         const uint32_t mask = (1u << width) - 1u;
         hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(ST), 0, s, R, keys[cur], shift, mask, nblocks, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(SCAN_T), 0, s, nblocks, hist, totals);
