@@ -67,6 +67,8 @@ class GaussianTrainer:
     Adam, so all ranks hold identical parameters.  The densification statistics are this rank's views only:
     ``sync_densification_stats()`` merges them over the ranks before densifying."""
 
+    _ROWS = ("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw")
+
     def __init__(self, scene, device, opt=None, spatial_lr_scale=1.0, factored_exchange=True,
                  densify_stats=True):
         self.opt = opt or OptimizationParams()
@@ -138,6 +140,41 @@ class GaussianTrainer:
         if self.densify_stats:
             m.max_radii2D = self.max_radii2D.float()
         return m
+
+    def capture(self):
+        """Everything a resumed run needs, as one dict of tensors and numbers -- the counterpart of
+        ``GaussianModel.capture()`` (gaussian_model.py:75-91) for ``torch.save((trainer.capture(), iteration))``
+        (train.py:130-132)."""
+        out = dict(iteration=self.iteration, sh_degree=self.sh_degree, max_sh_degree=self.max_sh_degree,
+                   spatial_lr_scale=self.spatial_lr_scale, adam_steps=dict(self.adam_steps),
+                   params={n: getattr(self, n).clone() for n in self._ROWS},
+                   exp_avg={n: self.state[n][0].clone() for n in self._ROWS},
+                   exp_avg_sq={n: self.state[n][1].clone() for n in self._ROWS},
+                   extras={n: t.clone() for n, t in self.extras.items()})
+        if self.densify_stats:
+            out["stats"] = dict(xyz_gradient_accum=self.xyz_gradient_accum.clone(), denom=self.denom.clone(),
+                                max_radii2D=self.max_radii2D.clone())
+        return out
+
+    def restore(self, captured):
+        """Inverse of ``capture()`` (gaussian_model.py:93-113); the trainer continues bit for bit."""
+        dev = self.xyz.device
+        f = lambda t: t.detach().to(dev).contiguous().clone()
+        for n in self._ROWS:
+            setattr(self, n, f(captured["params"][n]))
+            self.state[n] = (f(captured["exp_avg"][n]), f(captured["exp_avg_sq"][n]))
+        self.extras = {n: f(t) for n, t in captured["extras"].items()}
+        self.iteration, self.sh_degree = int(captured["iteration"]), int(captured["sh_degree"])
+        self.max_sh_degree, self.spatial_lr_scale = int(captured["max_sh_degree"]), captured["spatial_lr_scale"]
+        self.adam_steps = dict(captured["adam_steps"])
+        self.M = self.features.shape[1]
+        self._activate()
+        self._resized()
+        if self.densify_stats and "stats" in captured:
+            st = captured["stats"]
+            self.xyz_gradient_accum, self.denom, self.max_radii2D = (f(st["xyz_gradient_accum"]), f(st["denom"]),
+                                                                      f(st["max_radii2D"]))
+        return self
 
     def _resized(self):
         """(Re)build everything whose size follows the number of Gaussians: gradient buffers, statistics."""
@@ -248,8 +285,6 @@ class GaussianTrainer:
         self.max_radii2D[vis] = torch.max(self.max_radii2D[vis], radii[vis])
         self.xyz_gradient_accum[vis] += torch.norm(dL_dmeans2D[vis, :2], dim=-1, keepdim=True)
         self.denom[vis] += 1
-
-    _ROWS = ("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw")
 
     def _append_rows(self, new, new_extras):
         """gaussian_model.py:444-488: new Gaussians start with zero Adam moments; the statistics restart."""

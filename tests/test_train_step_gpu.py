@@ -570,3 +570,40 @@ def test_point_cloud_to_trained_ply(C, tmp_path):
     for a, b in zip(out.parameters(), back.parameters()):
         assert torch.equal(a.detach(), b.detach())
     assert back._xyz.shape == (tr.P, 3) and torch.isfinite(back._xyz).all()
+
+
+def test_capture_restore_resumes_bit_for_bit(C, tmp_path):
+    """A checkpoint written mid-run (after densifications, so sizes and step counts have moved) and restored into
+    a fresh trainer reproduces the whole state bit for bit; both then follow the same schedule.  (Their parameters
+    drift apart at rounding level afterwards: float atomics add in a different order from run to run.)"""
+    o = train_step.OptimizationParams()
+    o.iterations, o.densify_from_iter, o.densification_interval = 20, 1, 3
+    o.opacity_reset_interval, o.densify_until_iter = 6, 15
+    cam = make_camera(96, 64, synthetic.FOVX, (0.7, 0.5, -4.0), device=DEV)
+    gt = torch.rand(3, 64, 96, generator=torch.Generator().manual_seed(2)).to(DEV)
+    bg = torch.zeros(3, device=DEV)
+    run = lambda t: t.train_iteration(cam, gt, bg, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), scene_extent=2.0)
+    a = _small_trainer(2000, seed=4, log_scale=(-3.9, -2.9))
+    a.opt = o
+    a.extras["normals"] = torch.zeros(a.P, 3, device=DEV)
+    for _ in range(7):
+        run(a)
+    path = str(tmp_path / "chkpnt7.pth")
+    torch.save((a.capture(), a.iteration), path)
+    captured, it = torch.load(path, weights_only=True)
+    b = _small_trainer(10, seed=1)
+    b.opt = o
+    b.restore(captured)
+    assert it == 7 == b.iteration and b.P == a.P != 2000 and b.adam_steps == a.adam_steps
+    for n in a._ROWS:
+        assert torch.equal(getattr(a, n), getattr(b, n))
+        assert torch.equal(a.state[n][0], b.state[n][0]) and torch.equal(a.state[n][1], b.state[n][1])
+    assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and torch.equal(a.max_radii2D, b.max_radii2D)
+    assert torch.equal(a.scales, b.scales) and b.extras["normals"].shape == (b.P, 3)
+    for _ in range(5):
+        run(a)
+        run(b)
+    torch.cuda.synchronize()
+    assert a.iteration == b.iteration == 12 and a.adam_steps == b.adam_steps
+    assert abs(a.P - b.P) <= max(4, a.P // 100)
+    assert all(torch.isfinite(t).all() for t in (b.xyz, b.features, b.opacity_raw, b.scaling_raw, b.rotation_raw))
