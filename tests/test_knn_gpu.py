@@ -1,6 +1,8 @@
 """GPU parity of the nearest-neighbour routine (through the C ABI) against the checker's restatement of the
 reference's simple-knn.  Bar: bit-exact -- both evaluate dx*dx + dy*dy + dz*dz without contraction, the search is
 exact on both sides, and the mean is formed in the same order."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -30,6 +32,19 @@ def test_knn_matches_oracle(kind, P, dist2, oracle):
 @pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 63, 64, 65, 127, 4095, 4096, 4097, 4161])
 def test_knn_ragged_sizes(P, dist2, oracle):
     pts = knn_points("uniform", P, seed=P)
+    got = dist2(torch.tensor(pts, device=DEV)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.knn_mean_dist2(pts))
+
+
+# NGS_RANDOM_CONFIGS=N widens the sweep for a soak run
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NGS_RANDOM_CONFIGS", "6"))))
+def test_knn_random_sweep(seed, dist2, oracle):
+    rng = np.random.RandomState(5000 + seed)
+    kind = ("uniform", "clusters", "plane", "duplicates", "positive_octant")[rng.randint(0, 5)]
+    P = int(rng.choice([rng.randint(1, 300), rng.randint(300, 9000), rng.randint(9000, 60000)]))
+    pts = knn_points(kind, P, seed=seed)
+    if rng.rand() < 0.3:  # anisotropic extent: one axis dominates the Morton code
+        pts = pts * np.array([1.0, 10.0 ** rng.uniform(-3, 0), 10.0 ** rng.uniform(-3, 0)], np.float32)
     got = dist2(torch.tensor(pts, device=DEV)).cpu().numpy()
     np.testing.assert_array_equal(got, oracle.knn_mean_dist2(pts))
 
