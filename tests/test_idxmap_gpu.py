@@ -1,6 +1,7 @@
 """GPU parity of the index-map operators (through the C ABI) against the checker's restatement of the reference's
 scan / key / sort / range pipeline.  Bar: index map, depth map and the copied features bit-exact; view direction
 and its positional encoding within 2e-6 (device vs host sin/cos/sqrt); the backward sum within float addition order."""
+import os
 
 import numpy as np
 import pytest
@@ -52,6 +53,31 @@ def test_idxmap_forward_matches_oracle(name, r2, oracle):
     np.testing.assert_allclose(col.cpu().numpy(), o["color"], rtol=0, atol=2e-6)
     hit = o["idx"] >= 0
     assert hit.any() and (not hit.all() or name == "inside_cloud_big_squares")
+
+
+# NGS_RANDOM_CONFIGS=N widens the sweep for a soak run
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NGS_RANDOM_CONFIGS", "6"))))
+def test_idxmap_random_sweep(seed, r2, oracle):
+    rng = np.random.RandomState(7000 + seed)
+    W, H = int(rng.randint(9, 200)), int(rng.randint(9, 150))
+    P = int(rng.randint(1, 6000))
+    eye = (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-4.5, -0.3)))
+    means, vm, pm, fv, campos = idxmap_case(P, W, H, seed=seed, eye=eye)
+    o = oracle.idxmap_forward(means, vm, pm, fv, campos, W, H)
+    n, idx, col, dep, feat = run_hip(r2, means, vm, pm, fv, campos, W, H)
+    assert n == o["num_rendered"]
+    np.testing.assert_array_equal(idx.cpu().numpy(), o["idx"])
+    np.testing.assert_array_equal(dep.cpu().numpy().view(np.uint32), o["depth"].view(np.uint32))
+    f = feat.cpu().numpy()
+    np.testing.assert_array_equal(f[..., 25:], o["feature"][..., 25:])
+    np.testing.assert_allclose(f[..., 1:25], o["feature"][..., 1:25], rtol=0, atol=2e-6)
+    g = rng.randn(H, W, 64).astype(np.float32)
+    want = oracle.idxmap_backward(len(means), o["idx"], g)
+    got = r2._C.get_idxmap_backward2(torch.tensor(means, device=DEV), H, W, torch.tensor(campos, device=DEV),
+                                     torch.tensor(o["idx"], device=DEV), torch.tensor(g, device=DEV), False,
+                                     viewmatrix=torch.tensor(vm, device=DEV), projmatrix=torch.tensor(pm, device=DEV))[0]
+    got = got.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * max(1.0, float(np.abs(want).max())))
 
 
 def test_idxmap_debug_mode_and_no_count(r2, oracle):
