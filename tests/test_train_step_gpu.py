@@ -50,6 +50,23 @@ def test_fused_loss_matches_torch_formulation(C, H, W):
     assert float((dL - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
 
+# NGS_RANDOM_CONFIGS=N widens the sweep for a soak run
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NGS_RANDOM_CONFIGS", "6"))))
+def test_fused_loss_random_sizes(C, seed):
+    rng = np.random.RandomState(9000 + seed)
+    H, W = int(rng.randint(1, 200)), int(rng.randint(1, 300))
+    lam = float(rng.choice([0.2, 0.0, 1.0, 0.5]))
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(3, H, W, generator=g).to(DEV).requires_grad_(True)
+    gt = (torch.rand(3, H, W, generator=g) if seed % 3 else img.detach().cpu() + 0.01 * torch.randn(3, H, W, generator=g)).to(DEV)
+    loss = loss_utils.training_loss(img, gt, lam)
+    loss.backward()
+    terms, dL = C.l1_ssim_loss(img.detach(), gt, lam)
+    assert abs(float(terms[2]) - loss.item()) < 2e-6
+    ref = img.grad
+    assert float((dL - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-9
+
+
 def _torch_adam(params, lrs, grads_per_step, eps=1e-15):
     opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(params, lrs)], lr=0.0, eps=eps)
     for grads in grads_per_step:
