@@ -140,9 +140,11 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfov
 
 
 def backward(s, dL_dpix, means3D, viewmatrix, projmatrix, campos, bg, tanfovx, tanfovy, shs=None,
-             colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0):
+             colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, stage1=None):
     """Gradients in the layout of ``RasterizeGaussiansBackwardCUDA``
-    (submodules/diff-gaussian-rasterization/rasterize_points.cu:151-159)."""
+    (submodules/diff-gaussian-rasterization/rasterize_points.cu:151-159).
+    ``stage1`` = dict(dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors) replaces the compositing stage's sums by the
+    given ones, so that the per-Gaussian chain after it can be compared on identical inputs."""
     L = lib()
     P, W, H, M, D = s["P"], s["W"], s["H"], s["M"], s["D"]
     means3D = _f32(means3D)
@@ -159,10 +161,14 @@ def backward(s, dL_dpix, means3D, viewmatrix, projmatrix, campos, bg, tanfovx, t
         dL_drotations=np.zeros((P, 4), np.float32))
     if P == 0:
         return g
-    L.ngs_oracle_render_backward(W, H, _p(s["ranges"]), _p(s["point_list"]), _p(bg), _p(s["means2D"]),
-                                 _p(s["conic_opacity"]), _p(s["features"]), _p(s["final_T"]), _p(s["n_contrib"]),
-                                 _p(dL_dpix), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]),
-                                 _p(g["dL_dcolors"]))
+    if stage1 is not None:
+        for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors"):
+            g[k][...] = np.asarray(stage1[k], np.float32).reshape(g[k].shape)
+    else:
+        L.ngs_oracle_render_backward(W, H, _p(s["ranges"]), _p(s["point_list"]), _p(bg), _p(s["means2D"]),
+                                     _p(s["conic_opacity"]), _p(s["features"]), _p(s["final_T"]), _p(s["n_contrib"]),
+                                     _p(dL_dpix), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]),
+                                     _p(g["dL_dcolors"]))
     fy = np.float32(H) / (np.float32(2.0) * np.float32(tanfovy))
     fx = np.float32(W) / (np.float32(2.0) * np.float32(tanfovx))
     cov3d = cov3D_precomp if cov3D_precomp is not None and cov3D_precomp.size else s["cov3D"]

@@ -113,6 +113,28 @@ def check_grads(hg, og, scale=1.0, knife_edge_pixels=0):
         assert err / scale <= slack * max(GRAD_ATOL, noise * big / scale), "%s: abs err %g" % (name, err / scale)
 
 
+STAGE1 = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors")
+
+
+def check_grads_by_stage(oracle, c, o, dL, hg, scale, knife_edge_pixels=0):
+    """The backward pass in its two stages.  The compositing stage's per-Gaussian sums (view-space position, conic,
+    opacity, colour) against the checker's, within the summation bars of ``check_grads``.  Then the per-Gaussian
+    chain (screen-space covariance, projection, SH, scale and rotation) on IDENTICAL inputs: the checker is fed
+    the library's own sums, so only the arithmetic of that stage is compared -- tightly.  Judged end to end those
+    gradients would inherit the first stage's rounding noise through a chain that cancels heavily for splats near
+    the low-pass floor (1 / det^2 factors), which no fixed relative bar describes."""
+    og = oracle_backward(oracle, c, o, dL)
+    check_grads({k: hg[k] for k in STAGE1}, {k: og[k] for k in STAGE1}, scale, knife_edge_pixels)
+    og2 = oracle_backward(oracle, c, o, dL, stage1={k: hg[k] for k in STAGE1})
+    for name, ref in og2.items():
+        if name in STAGE1:
+            continue
+        got = hg[name].reshape(ref.shape)
+        big = float(np.abs(ref).max()) if ref.size else 0.0
+        err = float(np.abs(got - ref).max()) if ref.size else 0.0
+        assert err <= 1e-5 * big + 1e-12, "%s (same stage-1 sums): max err %g vs max magnitude %g" % (name, err, big)
+
+
 CASES = {
     "c1_sh0_64x64": dict(P=256, W=64, H=64, D=0),
     "sh3_64x64": dict(P=300, W=64, H=64, D=3, M=16, seed=7),
@@ -145,8 +167,11 @@ def test_random_configurations(seed, dgr, oracle):
     """Random image sizes (not multiples of the tile size), counts, footprints, SH degrees and eye positions."""
     rng = np.random.RandomState(1000 + seed)
     D = int(rng.randint(0, 4))
-    lo = float(rng.uniform(-5.5, -2.5))
-    c = case(P=int(rng.randint(30, 4000)), W=int(rng.randint(17, 260)), H=int(rng.randint(17, 200)), D=D,
+    big = os.environ.get("NGS_RANDOM_BIG") == "1"  # soak runs: up to 150 k Gaussians on up to 900 x 700 pixels
+    lo = float(rng.uniform(-5.5, -3.5 if big else -2.5))
+    c = case(P=int(rng.randint(1000, 150000) if big else rng.randint(30, 4000)),
+             W=int(rng.randint(100, 900) if big else rng.randint(17, 260)),
+             H=int(rng.randint(100, 700) if big else rng.randint(17, 200)), D=D,
              M=int(rng.choice([(D + 1) ** 2, 16])), log_scale=(lo, lo + float(rng.uniform(0.2, 2.0))), seed=seed,
              eye=(float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-4.5, -0.8))),
              bg=tuple(float(v) for v in rng.uniform(0, 1, 3)))
@@ -154,7 +179,7 @@ def test_random_configurations(seed, dgr, oracle):
     o = oracle_forward(oracle, c)
     h = run_hip(dgr, c, dL_dpix=dL)
     edge = check_forward(o, h, exact_pixels=False)
-    check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=float(c["W"] * c["H"]), knife_edge_pixels=edge)
+    check_grads_by_stage(oracle, c, o, dL, h["grads"], float(c["W"] * c["H"]), knife_edge_pixels=edge)
 
 
 def test_nonfinite_inputs_neither_hang_nor_fault(dgr):
