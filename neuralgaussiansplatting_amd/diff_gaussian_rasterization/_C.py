@@ -189,7 +189,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dopacity = mk("dL_dopacity", (P, 1))
     dL_dcov3D = mk("dL_dcov3D", (P, 6))
     dL_dsh = None if (skip_sh or sh_adam is not None) else mk("dL_dsh", (P, M, 3))
-    if sh_adam is not None:
+    if sh_adam is not None and P != 0:  # a scene pruned down to nothing has nothing to step
         if sh.numel() == 0 or M != 16:
             raise RuntimeError("the fused SH optimiser step needs SH coefficients of shape (P, 16, 3)")
         for t in (sh_adam["exp_avg"], sh_adam["exp_avg_sq"]):

@@ -624,3 +624,35 @@ def test_capture_restore_resumes_bit_for_bit(C, tmp_path):
     assert a.iteration == b.iteration == 12 and a.adam_steps == b.adam_steps
     assert abs(a.P - b.P) <= max(4, a.P // 100)
     assert all(torch.isfinite(t).all() for t in (b.xyz, b.features, b.opacity_raw, b.scaling_raw, b.rotation_raw))
+
+
+# NGS_RANDOM_CONFIGS=N widens the sweep for a soak run
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NGS_RANDOM_CONFIGS", "4"))))
+def test_trainer_random_sizes(C, seed):
+    """Any number of Gaussians (gradient buffers, Adam kernels and the fused SH step see unaligned sizes after
+    every densification) and any image size: a compressed schedule must run through with finite parameters."""
+    rng = np.random.RandomState(11000 + seed)
+    P = int(rng.choice([rng.randint(1, 8), rng.randint(8, 300), rng.randint(300, 5000)]))
+    W, H = int(rng.randint(8, 200)), int(rng.randint(8, 150))
+    lo = float(rng.uniform(-4.5, -2.0))
+    sc = synthetic.make_scene(P, 3, (lo, lo + 1.0), (1.3, 1.3, 1.3), seed=seed, sh_coeffs=16)
+    tr = train_step.GaussianTrainer(sc, DEV)
+    o = train_step.OptimizationParams()
+    o.iterations, o.densify_from_iter, o.densification_interval = 8, 1, 2
+    o.opacity_reset_interval, o.densify_until_iter = 4, 8
+    o.densify_grad_threshold = float(10.0 ** rng.uniform(-7, -3))
+    tr.opt = o
+    tr.sh_degree = int(rng.randint(0, 4))
+    cam = make_camera(W, H, synthetic.FOVX, (float(rng.uniform(-1, 1)), 0.4, float(rng.uniform(-4.5, -2.5))), device=DEV)
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    bg = torch.rand(3, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    for _ in range(o.iterations):
+        terms, color, radii = tr.train_iteration(cam, gt, bg, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                                                 scene_extent=float(rng.uniform(0.5, 5.0)),
+                                                 white_background=bool(seed % 2))
+        assert color.shape == (3, H, W)
+    torch.cuda.synchronize()
+    assert torch.isfinite(terms).all()
+    for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw):
+        assert t.shape[0] == tr.P and torch.isfinite(t).all()
+    assert tr.opacities.shape == (tr.P, 1) and tr.exchange.P == tr.P
