@@ -46,15 +46,16 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void masked_color_from_acc_kernel(
     out[3 * i + 2] = row[8] * ((bits & 4u) ? 0.0f : 1.0f);
 }
 
-// One lane per Gaussian.  LDS: M == 16, the 64 rows of a wave (12 KiB contiguous) leave through LDS as coalesced
-// 16-byte stores instead of 64 scattered 192-byte rows.
-template <bool LDS>
+// One lane per Gaussian.  LDS: M == 16, the 64 rows of a wave (12 KiB contiguous in memory) leave through LDS as
+// coalesced 16-byte stores instead of 64 scattered 192-byte rows.
+// TURNS: in how many turns a wave's 64 rows pass through LDS (1 or 2).
+template <bool LDS, int TURNS>
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void sh_from_views_kernel(
     int P, int D, int M, int V, const float* __restrict__ means, const float* __restrict__ campos,
     long long campos_stride, const float* __restrict__ colors, long long colors_stride, float* __restrict__ dL_dsh,
     const ShAdamArgs adam)
 {
-    __shared__ float s_sh[LDS ? NGS_GAUSS_BLOCK * SH_ROW_LDS : 1];
+    __shared__ float s_sh[LDS ? (NGS_GAUSS_BLOCK / TURNS) * SH_ROW_LDS : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + tid;
     const size_t i = (size_t)idx;
@@ -80,33 +81,45 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void sh_from_views_kernel(
         }
     }
     if (LDS) {
-        float* const wrows = s_sh + wave * 64 * SH_ROW_LDS;
-        float3* const row = (float3*)(wrows + lane * SH_ROW_LDS);
-#pragma unroll
-        for (int k = 0; k < 16; k++) row[k] = acc[k];
-        __builtin_amdgcn_wave_barrier();  // rows are wave-private and a wave's LDS operations complete in order
+        // With TURNS == 2 the wave's rows leave in two turns of 32 (lanes 0..31, then 32..63): half the LDS, so that
+        // it does not cap the waves per SIMD; every store instruction still writes 1 KiB of consecutive memory.
+        // (Worth 7 % for the plain gradient; the fused optimiser step is bound by its 3.5 GB of traffic and keeps one
+        // turn, which needs fewer registers.)
+        constexpr int ROWS = 64 / TURNS;
+        float* const wrows = s_sh + wave * ROWS * SH_ROW_LDS;
         const int wave_first = blockIdx.x * NGS_GAUSS_BLOCK + wave * 64;
 #pragma unroll
-        for (int t = 0; t < SH_ROW * 64 / 4 / 64; t++) {
-            const int f = t * 64 + lane, g = f / (SH_ROW / 4), c = f - g * (SH_ROW / 4);
-            if (wave_first + g >= P) continue;
-            const float4 gr = *(const float4*)(wrows + g * SH_ROW_LDS + c * 4);
-            const size_t o = (size_t)(wave_first + g) * SH_ROW + 4 * c;
-            if (adam.param) {
-                // optimiser step fused in: the summed gradient is consumed here instead of being written out
-                float4 p = stream_load4(adam.param + o), m = stream_load4(adam.exp_avg + o),
-                       v = stream_load4(adam.exp_avg_sq + o);
-                const float s3 = c == 0 ? adam.step_head : adam.step_tail;  // elements 0..2 of a row: the DC term
-                p.x = adam_update(p.x, gr.x * adam.k.grad_scale, m.x, v.x, s3, adam.k);
-                p.y = adam_update(p.y, gr.y * adam.k.grad_scale, m.y, v.y, s3, adam.k);
-                p.z = adam_update(p.z, gr.z * adam.k.grad_scale, m.z, v.z, s3, adam.k);
-                p.w = adam_update(p.w, gr.w * adam.k.grad_scale, m.w, v.w, adam.step_tail, adam.k);
-                stream_store4(adam.param + o, p);
-                stream_store4(adam.exp_avg + o, m);
-                stream_store4(adam.exp_avg_sq + o, v);
-            } else {
-                stream_store4(dL_dsh + o, gr);
+        for (int half = 0; half < TURNS; half++) {
+            if (lane / ROWS == half) {
+                float3* const row = (float3*)(wrows + (lane % ROWS) * SH_ROW_LDS);
+#pragma unroll
+                for (int k = 0; k < 16; k++) row[k] = acc[k];
             }
+            __builtin_amdgcn_wave_barrier();  // rows are wave-private and a wave's LDS operations complete in order
+#pragma unroll
+            for (int t = 0; t < SH_ROW * ROWS / 4 / 64; t++) {
+                const int f = t * 64 + lane, g = f / (SH_ROW / 4), c = f - g * (SH_ROW / 4);
+                const int gi = wave_first + half * ROWS + g;
+                if (gi >= P) continue;
+                const float4 gr = *(const float4*)(wrows + g * SH_ROW_LDS + c * 4);
+                const size_t o = (size_t)gi * SH_ROW + 4 * c;
+                if (adam.param) {
+                    // optimiser step fused in: the summed gradient is consumed here instead of being written out
+                    float4 p = stream_load4(adam.param + o), m = stream_load4(adam.exp_avg + o),
+                           v = stream_load4(adam.exp_avg_sq + o);
+                    const float s3 = c == 0 ? adam.step_head : adam.step_tail;  // elements 0..2 of a row: the DC term
+                    p.x = adam_update(p.x, gr.x * adam.k.grad_scale, m.x, v.x, s3, adam.k);
+                    p.y = adam_update(p.y, gr.y * adam.k.grad_scale, m.y, v.y, s3, adam.k);
+                    p.z = adam_update(p.z, gr.z * adam.k.grad_scale, m.z, v.z, s3, adam.k);
+                    p.w = adam_update(p.w, gr.w * adam.k.grad_scale, m.w, v.w, adam.step_tail, adam.k);
+                    stream_store4(adam.param + o, p);
+                    stream_store4(adam.exp_avg + o, m);
+                    stream_store4(adam.exp_avg_sq + o, v);
+                } else {
+                    stream_store4(dL_dsh + o, gr);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     } else if (idx < P) {
         float3* out = (float3*)(dL_dsh + (size_t)3 * M * i);
@@ -137,10 +150,13 @@ void ngs_launch_sh_from_views(hipStream_t s, int P, int D, int M, int V, const f
     ShAdamArgs adam;
     memset(&adam, 0, sizeof adam);
     if (sh_adam) adam = *sh_adam;  // the caller has checked M == 16 and the alignment
-    if (M == 16 && (uintptr_t)dL_dsh % 16 == 0)
-        hipLaunchKernelGGL(sh_from_views_kernel<true>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, V, means, campos,
-                           campos_stride, colors, colors_stride, dL_dsh, adam);
+    if (M == 16 && (uintptr_t)dL_dsh % 16 == 0 && adam.param)
+        hipLaunchKernelGGL((sh_from_views_kernel<true, 1>), dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, V, means,
+                           campos, campos_stride, colors, colors_stride, dL_dsh, adam);
+    else if (M == 16 && (uintptr_t)dL_dsh % 16 == 0)
+        hipLaunchKernelGGL((sh_from_views_kernel<true, 2>), dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, V, means,
+                           campos, campos_stride, colors, colors_stride, dL_dsh, adam);
     else
-        hipLaunchKernelGGL(sh_from_views_kernel<false>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, V, means,
+        hipLaunchKernelGGL((sh_from_views_kernel<false, 1>), dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, V, means,
                            campos, campos_stride, colors, colors_stride, dL_dsh, adam);
 }
