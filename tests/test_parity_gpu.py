@@ -116,16 +116,16 @@ def check_grads(hg, og, scale=1.0, knife_edge_pixels=0):
 STAGE1 = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors")
 
 
-def check_grads_by_stage(oracle, c, o, dL, hg, scale, knife_edge_pixels=0):
+def check_grads_by_stage(oracle, c, o, dL, hg, scale, knife_edge_pixels=0, **paths):
     """The backward pass in its two stages.  The compositing stage's per-Gaussian sums (view-space position, conic,
     opacity, colour) against the checker's, within the summation bars of ``check_grads``.  Then the per-Gaussian
     chain (screen-space covariance, projection, SH, scale and rotation) on IDENTICAL inputs: the checker is fed
     the library's own sums, so only the arithmetic of that stage is compared -- tightly.  Judged end to end those
     gradients would inherit the first stage's rounding noise through a chain that cancels heavily for splats near
     the low-pass floor (1 / det^2 factors), which no fixed relative bar describes."""
-    og = oracle_backward(oracle, c, o, dL)
+    og = oracle_backward(oracle, c, o, dL, **paths)
     check_grads({k: hg[k] for k in STAGE1}, {k: og[k] for k in STAGE1}, scale, knife_edge_pixels)
-    og2 = oracle_backward(oracle, c, o, dL, stage1={k: hg[k] for k in STAGE1})
+    og2 = oracle_backward(oracle, c, o, dL, stage1={k: hg[k] for k in STAGE1}, **paths)
     for name, ref in og2.items():
         if name in STAGE1:
             continue
@@ -176,10 +176,20 @@ def test_random_configurations(seed, dgr, oracle):
              eye=(float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-4.5, -0.8))),
              bg=tuple(float(v) for v in rng.uniform(0, 1, 3)))
     dL = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(seed))
-    o = oracle_forward(oracle, c)
-    h = run_hip(dgr, c, dL_dpix=dL)
+    # one run in three takes another input path: precomputed colours, precomputed covariance, a scale modifier
+    paths = {}
+    variant = int(rng.randint(0, 9))
+    if variant in (0, 2):
+        paths["colors_precomp"] = torch.rand(c["scene"].means3D.shape[0], 3, generator=torch.Generator().manual_seed(seed))
+    if variant in (1, 2):
+        from neuralgaussiansplatting_amd.gaussian_model import covariance_from_scaling_rotation
+        paths["cov3D_precomp"] = covariance_from_scaling_rotation(c["scene"].scales, 1.0, c["scene"].rotations).contiguous()
+    if variant == 3:
+        paths["scale_modifier"] = float(rng.uniform(0.3, 2.0))
+    o = oracle_forward(oracle, c, **paths)
+    h = run_hip(dgr, c, dL_dpix=dL, **paths)
     edge = check_forward(o, h, exact_pixels=False)
-    check_grads_by_stage(oracle, c, o, dL, h["grads"], float(c["W"] * c["H"]), knife_edge_pixels=edge)
+    check_grads_by_stage(oracle, c, o, dL, h["grads"], float(c["W"] * c["H"]), knife_edge_pixels=edge, **paths)
 
 
 def test_nonfinite_inputs_neither_hang_nor_fault(dgr):
