@@ -656,3 +656,28 @@ def test_trainer_random_sizes(C, seed):
     for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw):
         assert t.shape[0] == tr.P and torch.isfinite(t).all()
     assert tr.opacities.shape == (tr.P, 1) and tr.exchange.P == tr.P
+
+
+def test_activated_adam_aligned_and_unaligned_paths_agree(C):
+    """16-byte aligned arrays take the float4 kernel, anything else the scalar one: same bits either way."""
+    gen = torch.Generator().manual_seed(21)
+    for P in (1, 2, 3, 5, 64, 259, 1002):
+        data = [[torch.randn(P * w + 1, generator=gen) for w in (1, 3, 4)] for _ in range(4)]  # raw, grad, m, v
+        data[3] = [t.abs() * 1e-3 for t in data[3]]
+        results = []
+        for shift in (0, 1):  # shift 1: opacity and scale arrays start 4 bytes off a 16-byte boundary
+            groups = []
+            for arrays in data:
+                views = []
+                for t, w in zip(arrays, (1, 3, 4)):
+                    if w == 4 or shift == 0:
+                        views.append(t[:P * w].clone().to(DEV).view(P, w))
+                    else:
+                        views.append(torch.cat([torch.zeros(1), t[:P * w]]).to(DEV)[1:].view(P, w))
+                groups.append(views)
+            act = [torch.empty(P * w + 4, device=DEV)[shift if w != 4 else 0:][:P * w].view(P, w) for w in (1, 3, 4)]
+            assert all(v.is_contiguous() for grp in groups for v in grp)
+            C.adam_step_activated(groups[0], groups[1], groups[2], groups[3], act, (0.05, 0.005, 0.001), (3, 4, 4))
+            results.append([t.clone() for t in groups[0] + groups[2] + groups[3] + act])
+        for a, b in zip(*results):
+            assert torch.equal(a, b), P
