@@ -1,7 +1,6 @@
 """Shared helpers for the parity tests: scene/camera cases and state-buffer decoding."""
 import math
 
-import numpy as np
 import torch
 
 from neuralgaussiansplatting_amd import synthetic
