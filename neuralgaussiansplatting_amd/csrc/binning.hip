@@ -10,24 +10,53 @@
 #include "ngs_common.h"
 
 #define SCAN_THREADS 1024
+#define SCAN_REGS 8
 
 // Exclusive scan of the per-block tile counts by a single workgroup.  Thread t
-// owns a contiguous run of ceil(n/1024) entries.
+// owns a contiguous run of entries (a multiple of four).
 __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, const uint32_t* __restrict__ in,
                                                                         uint32_t* __restrict__ out,
                                                                         uint32_t* __restrict__ misc,
                                                                         unsigned long long* mailbox)
 {
     __shared__ uint32_t wave_tot[SCAN_THREADS / 64];
-    const int per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
+    // A thread's run is a whole number of 16-byte groups; up to SCAN_REGS groups (8.4 M Gaussians) are fetched with
+    // independent vector loads and stay in registers for the second sweep -- one memory round trip instead of one per
+    // entry.  Longer runs fall back to two scalar sweeps.
+    const int groups = (n + 4 * SCAN_THREADS - 1) / (4 * SCAN_THREADS);
+    const int per = 4 * groups;
     const int lo = threadIdx.x * per;
     const int hi = min(n, lo + per);
+    const bool in_regs = groups <= SCAN_REGS;
     __shared__ unsigned long long wave_wide[SCAN_THREADS / 64];
     uint32_t s = 0;
     unsigned long long wide = 0;  // the same sum without wrap-around, to notice a count that does not fit
-    for (int i = lo; i < hi; i++) {
-        s += in[i];
-        wide += in[i];
+    uint4 held[SCAN_REGS];
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < SCAN_REGS; j++) {
+            held[j] = make_uint4(0, 0, 0, 0);
+            const int at = lo + 4 * j;
+            if (j < groups && at < n) {
+                if (at + 4 <= n) {
+                    held[j] = *(const uint4*)(in + at);
+                } else {
+                    held[j].x = in[at];
+                    if (at + 1 < n) held[j].y = in[at + 1];
+                    if (at + 2 < n) held[j].z = in[at + 2];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SCAN_REGS; j++) {
+            s += held[j].x + held[j].y + held[j].z + held[j].w;
+            wide += (unsigned long long)held[j].x + held[j].y + held[j].z + held[j].w;
+        }
+    } else {
+        for (int i = lo; i < hi; i++) {
+            s += in[i];
+            wide += in[i];
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t incl = wave_incl_scan_u32(s, lane);
@@ -47,10 +76,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
         total_wide += wave_wide[w];
     }
     uint32_t run = base + incl - s;
-    for (int i = lo; i < hi; i++) {
-        const uint32_t v = in[i];
-        out[i] = run;
-        run += v;
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < SCAN_REGS; j++) {
+            const int at = lo + 4 * j;
+            uint4 o;
+            o.x = run; run += held[j].x;
+            o.y = run; run += held[j].y;
+            o.z = run; run += held[j].z;
+            o.w = run; run += held[j].w;
+            if (j < groups && at < n) {
+                if (at + 4 <= n) {
+                    *(uint4*)(out + at) = o;
+                } else {
+                    out[at] = o.x;
+                    if (at + 1 < n) out[at + 1] = o.y;
+                    if (at + 2 < n) out[at + 2] = o.z;
+                }
+            }
+        }
+    } else {
+        for (int i = lo; i < hi; i++) {
+            const uint32_t v = in[i];
+            out[i] = run;
+            run += v;
+        }
     }
     if (threadIdx.x == 0) {
         if (total_wide > 0x7fffffffull) {  // the count is handed on as a signed 32-bit number
