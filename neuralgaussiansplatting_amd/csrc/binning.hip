@@ -182,6 +182,37 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t L, const uint3
     if (idx == L - 1) ranges[cur].y = (uint32_t)L;
 }
 
+// The same with four keys per thread (one 16-byte load plus the key before them).
+__global__ __launch_bounds__(256) void tile_ranges_vec_kernel(int64_t L, const uint32_t* __restrict__ keys,
+                                                              uint2* __restrict__ ranges)
+{
+    const int64_t first = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (first >= L) return;
+    uint32_t k[4];
+    if (first + 4 <= L) {
+        const uint4 v = *(const uint4*)(keys + first);
+        k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+    } else {
+        for (int j = 0; j < 4; j++) k[j] = first + j < L ? keys[first + j] : 0u;
+    }
+    uint32_t prev = first > 0 ? keys[first - 1] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int64_t idx = first + j;
+        if (idx < L) {
+            const uint32_t cur = k[j];
+            if (idx == 0) {
+                ranges[cur].x = 0;
+            } else if (cur != prev) {
+                ranges[prev].y = (uint32_t)idx;
+                ranges[cur].x = (uint32_t)idx;
+            }
+            if (idx == L - 1) ranges[cur].y = (uint32_t)L;
+            prev = cur;
+        }
+    }
+}
+
 void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* block_sums, uint32_t* block_offs,
                                 uint32_t* misc, unsigned long long* mailbox)
 {
@@ -200,6 +231,8 @@ void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_
 void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint32_t* keys, int T, uint2* ranges)
 {
     (void)hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s);
-    if (R > 0)
+    if (R > 0 && (uintptr_t)keys % 16 == 0)
+        hipLaunchKernelGGL(tile_ranges_vec_kernel, dim3((unsigned)((R + 1023) / 1024)), dim3(256), 0, s, R, keys, ranges);
+    else if (R > 0)
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);
 }
