@@ -229,6 +229,27 @@ int ngs_idxmap_backward(int P, int width, int height, const float* means3D, cons
                         const float* projmatrix, int debug, void* stream);
 
 /*
+ * ngs_idxmap_forward for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference (whose binding allocates three
+ * scratch tensors per call, r2/rasterize_points.cu:205-213).  Same kernels and same results as ngs_idxmap_forward,
+ * but the z-buffer (8 bytes per pixel + 256) lives in a device array built into the library instead of a
+ * caller-supplied workspace, and the call itself allocates nothing, frees nothing and never synchronises.
+ *  - Limit: width * height <= NGS_IDXMAP_STATIC_MAX_PIXELS (2^21, enough for 1920x1080); larger images are refused
+ *    with an error.  Every GPU the library runs on holds its own 16 MiB + 256 B copy of the array until the process
+ *    ends.
+ *  - All calls on one GPU share that GPU's array: calls that overlap in time on the same GPU (different streams or
+ *    threads) race; calls on one stream, or otherwise ordered, are safe.  Each call resets what it uses.
+ *  - Arguments as ngs_idxmap_forward without the ones the reference ignores, the workspace and the debug flag;
+ *    num_rendered_device (may be NULL) is a DEVICE pointer that receives the entry count on the stream, so no host
+ *    synchronisation is needed; radii may be NULL.
+ */
+#define NGS_IDXMAP_STATIC_MAX_PIXELS (1 << 21)
+int ngs_idxmap_forward_static(int P, int width, int height, const float* means3D, const float* viewmatrix,
+                              const float* projmatrix, const float* feature_vector, const float* campos, int* out_idx,
+                              float* out_color, float* out_depth, float* out_feature, int* radii,
+                              int* num_rendered_device, void* stream);
+
+/*
  * Scene initialisation: mean_dist2[i] = mean of the squared distances from point i to its three nearest other
  * points = SimpleKNN::knn (submodules/simple-knn/simple_knn.h:16-19, simple_knn.cu:185-221), the routine behind
  * simple_knn._C.distCUDA2 (spatial.cu:15-26, ext.cpp:15-17), whose result scene/gaussian_model.py:160-161 turns into

@@ -17,6 +17,10 @@ static int fail(const char* what, const char* detail)
     return 1;
 }
 
+// for entry points defined in other translation units
+int ngs_set_error(const char* what, const char* detail) { return fail(what, detail); }
+void ngs_clear_error(void) { g_err[0] = 0; }
+
 #define NGS_HIP(call)                                                   \
     do {                                                                \
         hipError_t e_ = (call);                                         \

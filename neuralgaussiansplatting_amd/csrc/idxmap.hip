@@ -210,6 +210,13 @@ __global__ __launch_bounds__(256) void idxmap_backward_gather_kernel(int P, int 
 
 size_t ngs_idxmap_workspace_size(int W, int H) { return (size_t)W * H * 8 + 256; }
 
+// Sums the 64 partial entry counts into one device word (for callers that must not synchronise to read it).
+__global__ __launch_bounds__(64) void idxmap_count_kernel(const uint32_t* __restrict__ partial, int* __restrict__ out)
+{
+    const uint32_t total = wave_sum_u32(partial[threadIdx.x]);
+    if (threadIdx.x == 0) *out = (int)total;
+}
+
 void ngs_launch_idxmap_forward(hipStream_t s, int P, int W, int H, const float* means, const float* view,
                                const float* proj, const float* campos, const float* feature_vector, char* workspace,
                                int* out_idx, float* out_color, float* out_depth, float* out_feature, int* radii,
@@ -241,4 +248,83 @@ void ngs_launch_idxmap_backward(hipStream_t s, int P, int W, int H, const float*
     const size_t threads = (size_t)W * H * 16;
     hipLaunchKernelGGL(idxmap_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P, W, H,
                        out_idx, dL_dfeature, dL_dfeature_vector);
+}
+
+// ---------------------------------------------------------------------------
+// ngs_idxmap_forward_static: the forward pass for callers that cannot allocate device memory and cannot hand over a
+// workspace either (code under HIP graph capture, serving loops).  Its z-buffer lives in a file-scope device array
+// of fixed size; every call on a GPU shares that GPU's copy.
+// ---------------------------------------------------------------------------
+#include <stdio.h>
+
+#include <mutex>
+
+#include "../../include/ngs_rasterizer.h"
+
+#define IDX_STATIC_PIXELS NGS_IDXMAP_STATIC_MAX_PIXELS
+#define IDX_STATIC_BYTES ((size_t)IDX_STATIC_PIXELS * 8 + 256)
+#define IDX_STATIC_MAX_DEVICES 64
+
+// One copy per GPU the library runs on, held until the process ends.  In host code this name is only a handle
+// for hipGetSymbolAddress; the address kernels and memsets use is the one that call returns.
+static __device__ __align__(256) unsigned char scratch[IDX_STATIC_BYTES];
+
+static std::mutex g_static_lock;
+static char* g_static_ptr[IDX_STATIC_MAX_DEVICES];  // per device: address of that device's copy of `scratch`
+
+// Address of the current device's copy, resolved once per device with that device current.
+static hipError_t idx_static_workspace(char** out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= IDX_STATIC_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(g_static_lock);
+    if (!g_static_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_static_ptr[dev] = (char*)p;
+    }
+    *out = g_static_ptr[dev];
+    return hipSuccess;
+}
+
+static int static_fail(const char* what, const char* detail)
+{
+    char msg[256];
+    snprintf(msg, sizeof msg, "ngs_idxmap_forward_static: %s", what);
+    return ngs_set_error(msg, detail);
+}
+
+extern "C" int ngs_idxmap_forward_static(int P, int width, int height, const float* means3D, const float* viewmatrix,
+                                         const float* projmatrix, const float* feature_vector, const float* campos,
+                                         int* out_idx, float* out_color, float* out_depth, float* out_feature,
+                                         int* radii, int* num_rendered_device, void* stream)
+{
+    ngs_clear_error();
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0 || P > NGS_MAX_GAUSSIANS || width <= 0 || height <= 0) return static_fail("bad sizes", nullptr);
+    if (width > 32767 || height > 32767 || (long long)width * height > (long long)IDX_STATIC_PIXELS)
+        return static_fail("image larger than the built-in z-buffer (NGS_IDXMAP_STATIC_MAX_PIXELS pixels); "
+                           "use ngs_idxmap_forward with a workspace", nullptr);
+    if (!out_idx || !out_color || !out_depth || !out_feature) return static_fail("missing required pointer", nullptr);
+    if (P > 0 && (!means3D || !viewmatrix || !projmatrix || !feature_vector || !campos))
+        return static_fail("missing required pointer", nullptr);
+    if (((uintptr_t)out_feature | (uintptr_t)feature_vector) % 16 != 0)
+        return static_fail("feature arrays must be 16-byte aligned", nullptr);
+    char* ws = nullptr;
+    const hipError_t e = idx_static_workspace(&ws);
+    if (e != hipSuccess) return static_fail("hipGetSymbolAddress(scratch)", hipGetErrorString(e));
+    // ngs_launch_idxmap_forward resets the part of the workspace this image size uses (all-ones z-buffer, zeroed
+    // counters), so nothing of an earlier call's contents is read.
+    ngs_launch_idxmap_forward(st, P, width, height, means3D, viewmatrix, projmatrix, campos, feature_vector, ws,
+                              out_idx, out_color, out_depth, out_feature, radii, num_rendered_device != nullptr);
+    if (num_rendered_device)
+        hipLaunchKernelGGL(idxmap_count_kernel, dim3(1), dim3(64), 0, st,
+                           (const uint32_t*)(ws + (size_t)width * height * 8), num_rendered_device);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return static_fail("launch", hipGetErrorString(le));
+    return 0;
 }

@@ -162,6 +162,9 @@ struct ShAdamArgs {
 // ---------------------------------------------------------------------------
 // Stage launchers (each defined in the .hip file named in the comment).
 // ---------------------------------------------------------------------------
+// capi.hip: the calling thread's error message (what ngs_last_error returns); ngs_set_error returns 1
+int ngs_set_error(const char* what, const char* detail);
+void ngs_clear_error(void);
 // preprocess_fwd.hip
 void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* means, const float* scales, float mod,
                                const float* rots, const float* opac, const float* shs, const float* cov_pre,

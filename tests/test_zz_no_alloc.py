@@ -1,0 +1,105 @@
+"""ngs_idxmap_forward_static (the entry point that allocates nothing: its z-buffer is a device array built into the
+library) against ngs_idxmap_forward with a caller-supplied workspace, both through the C ABI.  Same kernels, so the
+bar is bit equality of every output.  Two calls in a row share the built-in array; the second one is smaller, so it
+would read stale z-buffer cells if a call did not reset what it uses."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from test_idxmap_cpu import idxmap_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lib():
+    from neuralgaussiansplatting_amd.rasterizer2 import _C as r2c
+    L = r2c._lib()
+    L.ngs_idxmap_forward_static.restype = ctypes.c_int
+    return L
+
+
+_calls = {"n": 0}
+
+
+def _outputs(W, H, P):
+    return dict(idx=torch.full((H, W), -7, dtype=torch.int32, device=DEV),
+                color=torch.full((H, W, 3), -7.0, device=DEV), depth=torch.full((H, W), -7.0, device=DEV),
+                feature=torch.full((H, W, 64), -7.0, device=DEV),
+                radii=torch.full((P,), -7, dtype=torch.int32, device=DEV))
+
+
+def _run_pair(L, P, W, H, seed, eye):
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization._C import _ptr, _stream
+    means, vm, pm, fv, campos = idxmap_case(P, W, H, seed=seed, eye=eye)
+    t = lambda a: torch.tensor(a, device=DEV)
+    means, vm, pm, fv, campos = t(means), t(vm), t(pm), t(fv), t(campos)
+    dev = torch.device(DEV)
+
+    ref = _outputs(W, H, P)
+    workspace = torch.empty(L.ngs_idxmap_workspace_bytes(W, H), dtype=torch.uint8, device=DEV)
+    n_ref = ctypes.c_int(0)
+    rc = L.ngs_idxmap_forward(P, 0, W, H, _ptr(means), None, None, None, _ptr(vm), _ptr(pm), ctypes.c_float(0.36),
+                              ctypes.c_float(0.36), _ptr(fv), None, _ptr(campos), _ptr(ref["idx"]),
+                              _ptr(ref["color"]), _ptr(ref["depth"]), _ptr(ref["feature"]), _ptr(ref["radii"]),
+                              _ptr(workspace), 0, _stream(dev), ctypes.byref(n_ref))
+    assert rc == 0, L.ngs_last_error().decode()
+
+    got = _outputs(W, H, P)
+    n_got = torch.full((1,), -7, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    rc = L.ngs_idxmap_forward_static(P, W, H, _ptr(means), _ptr(vm), _ptr(pm), _ptr(fv), _ptr(campos),
+                                     _ptr(got["idx"]), _ptr(got["color"]), _ptr(got["depth"]), _ptr(got["feature"]),
+                                     _ptr(got["radii"]), _ptr(n_got), _stream(dev))
+    assert rc == 0, L.ngs_last_error().decode()
+    torch.cuda.synchronize()
+    # device memory in use did not grow across the call (the first call on a device is exempt: the runtime may
+    # finish loading the library's code object lazily)
+    if _calls["n"] > 0:
+        assert torch.cuda.mem_get_info()[0] >= free_before
+    _calls["n"] += 1
+    for k in ref:
+        a, b = ref[k].cpu().numpy(), got[k].cpu().numpy()
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32), err_msg=k)
+    assert int(n_got.item()) == n_ref.value > 0
+    hit = ref["idx"] >= 0
+    assert hit.any() and not (ref["idx"] == -7).any()
+    return int(hit.sum().item())
+
+
+def test_static_idxmap_matches_workspace_variant_twice():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    L = _lib()
+    # first call: a large image that fills most cells of the built-in z-buffer it touches
+    big = _run_pair(L, 20000, 640, 400, seed=5, eye=(0.1, 0.05, -1.2))
+    # second call, smaller image and fewer, different Gaussians: stale cells of the first call must not show
+    small = _run_pair(L, 700, 96, 72, seed=11, eye=(0.3, 0.2, -3.5))
+    assert big > small > 0
+    # and a larger one again after the small one
+    _run_pair(L, 5000, 320, 200, seed=3, eye=(0.0, 0.0, -2.5))
+
+
+def test_static_idxmap_empty_scene_and_limits():
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization._C import _ptr, _stream
+    L = _lib()
+    dev = torch.device(DEV)
+    W, H = 40, 24
+    out = _outputs(W, H, 1)
+    eye4 = torch.eye(4, device=DEV)
+    # P == 0 after a populated call: every pixel must read "no centre"
+    rc = L.ngs_idxmap_forward_static(0, W, H, None, _ptr(eye4), _ptr(eye4), None, None, _ptr(out["idx"]),
+                                     _ptr(out["color"]), _ptr(out["depth"]), _ptr(out["feature"]), None, None,
+                                     _stream(dev))
+    assert rc == 0, L.ngs_last_error().decode()
+    torch.cuda.synchronize()
+    assert (out["idx"] == -1).all() and not out["feature"].any() and not out["depth"].any()
+    # one pixel more than the built-in buffer holds: refused with a message, nothing launched
+    rc = L.ngs_idxmap_forward_static(0, 2048, 1025, None, None, None, None, None, _ptr(out["idx"]), _ptr(out["color"]),
+                                     _ptr(out["depth"]), _ptr(out["feature"]), None, None, _stream(dev))
+    assert rc != 0 and b"larger than the built-in z-buffer" in L.ngs_last_error()
+    rc = L.ngs_idxmap_forward_static(5, W, H, None, None, None, None, None, _ptr(out["idx"]), _ptr(out["color"]),
+                                     _ptr(out["depth"]), _ptr(out["feature"]), None, None, _stream(dev))
+    assert rc != 0 and b"missing required pointer" in L.ngs_last_error()
