@@ -18,8 +18,9 @@
  * Return value: 0 on success, non-zero on failure; ngs_last_error() then
  * returns a message (thread-local storage, valid until the next call on that
  * thread).  Nothing is retained by the library between calls except one 64-byte
- * word of pinned host memory per calling thread, through which the instance
- * count reaches the host (NGS_NO_MAILBOX=1 in the environment disables it).
+ * word of pinned host memory per calling thread and device, through which the
+ * instance count reaches the host (never freed; NGS_NO_MAILBOX=1 in the
+ * environment disables it).
  */
 #ifndef NGS_RASTERIZER_H
 #define NGS_RASTERIZER_H
@@ -65,6 +66,7 @@ int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_a
  * they are re-carved from P, R and the image size).  Every output element is WRITTEN (zeros for culled Gaussians), so
  * the caller need not zero-fill; dL_dconic ([P][2][2]) may be NULL, and so may dL_dsh (the SH coefficient gradient
  * is then not produced; its share of dL_dmean3D still is -- see ngs_sh_gradient_from_views).
+ * rotations, dL_drot and dL_dconic must be 16-byte aligned (an error otherwise); D and M as in the forward call.
  * Shapes: dL_dpix [3][H][W]; dL_dmean2D [P][3]; dL_dopacity [P]; dL_dcolor
  * [P][3]; dL_dmean3D [P][3]; dL_dcov3D [P][6]; dL_dsh [P][M][3]; dL_dscale
  * [P][3]; dL_drot [P][4].

@@ -156,40 +156,52 @@ static NgsCamera make_camera(int W, int H, float tanx, float tany, const float* 
     return c;
 }
 
-// One 64-bit word of coherent pinned host memory per calling thread, written by the scan kernel and polled by the
-// host (see ngs_rasterize_forward).  Allocated on first use and kept for the life of the thread's process;
+// One 64-bit word of coherent pinned host memory per calling thread and device, written by the scan kernel and
+// polled by the host (see ngs_rasterize_forward).  Allocated on first use and never freed (a thread that ends
+// leaves its 64 bytes behind: freeing from a thread-exit hook could run after the HIP runtime has shut down);
 // NGS_NO_MAILBOX=1 disables it.
+#define NGS_MAX_DEVICES 64
 struct Mailbox {
     unsigned long long* host;
     unsigned long long* dev;
+    int state;  // 0 = not tried, 1 = ready, -1 = unavailable
 };
 
 static Mailbox* mailbox_get()
 {
-    static thread_local Mailbox mb = {nullptr, nullptr};
-    static thread_local int state = 0;  // 0 = not tried, 1 = ready, -1 = unavailable
-    if (state == 0) {
-        state = -1;
+    static thread_local Mailbox boxes[NGS_MAX_DEVICES];
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= NGS_MAX_DEVICES) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    Mailbox& mb = boxes[device];
+    if (mb.state == 0) {
+        mb.state = -1;
         const char* off = getenv("NGS_NO_MAILBOX");
         if (!(off && off[0] == '1')) {
             void* h = nullptr;
             void* d = nullptr;
+            // the device-side address is resolved with this device current: it is only ever handed to kernels
+            // launched on this device
             if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) ==
                     hipSuccess &&
                 hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
                 mb.host = (unsigned long long*)h;
                 mb.dev = (unsigned long long*)d;
-                state = 1;
+                mb.state = 1;
             } else {
                 (void)hipGetLastError();
             }
         }
     }
-    return state == 1 ? &mb : nullptr;
+    return mb.state == 1 ? &mb : nullptr;
 }
 
-// Spins until the scan kernel has posted its word; false after two seconds without it.
-static bool mailbox_wait(Mailbox* mb, uint32_t out[2])
+// Spins until the scan kernel has posted its word.  Returns false -- the caller then falls back to a copy and a
+// stream synchronisation, which also surfaces the error of a failed kernel -- when the stream has drained or
+// failed without the word arriving, or after two seconds.
+static bool mailbox_wait(Mailbox* mb, hipStream_t st, uint32_t out[2])
 {
     if (!mb) return false;
     const auto t0 = std::chrono::steady_clock::now();
@@ -200,9 +212,18 @@ static bool mailbox_wait(Mailbox* mb, uint32_t out[2])
             out[1] = (uint32_t)(v >> 32);
             return true;
         }
-        if ((spins & 1023u) == 1023u &&
-            std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
-            return false;
+        if ((spins & 4095u) == 4095u) {  // every ~150 us: far beyond a healthy wait, so a normal call never pays
+            if (hipStreamQuery(st) != hipErrorNotReady) {
+                (void)hipGetLastError();
+                // finished (or failed) -- one last look, the word is written before the kernel ends
+                const unsigned long long w = __atomic_load_n(mb->host, __ATOMIC_ACQUIRE);
+                if (w == ~0ull) return false;
+                out[0] = (uint32_t)w;
+                out[1] = (uint32_t)(w >> 32);
+                return true;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return false;
+        }
         __builtin_ia32_pause();
     }
 }
@@ -297,7 +318,7 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     // into pinned host memory and the host spins on them; if they do not arrive (a failed kernel, a platform
     // without coherent host memory) the wait falls back to a copy and a stream synchronisation.
     uint32_t host_misc[2] = {0, 0};
-    if (!mailbox_wait(mb, host_misc)) {
+    if (!mailbox_wait(mb, st, host_misc)) {
         NGS_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, st));
         NGS_HIP(hipStreamSynchronize(st));
     }
@@ -376,7 +397,12 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
         !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
         return fail(fn, "missing required pointer");
     if (shs && !campos) return fail(fn, "shs given without campos");
+    // the forward pass checks the same (the kernels index sh[0 .. (D+1)^2) of an M-wide row)
+    if (shs && (D < 0 || D > 3 || (D + 1) * (D + 1) > M)) return fail(fn, "SH degree does not fit the coefficient count");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(fn, "need scales+rotations or cov3D_precomp");
+    // the per-Gaussian kernel moves quaternions and their gradients (and the conic gradient) as 16-byte vectors
+    if ((((uintptr_t)dL_drot | (uintptr_t)dL_dconic) % 16 != 0) || (!cov3D_precomp && (uintptr_t)rotations % 16 != 0))
+        return fail(fn, "rotations, dL_drot and dL_dconic must be 16-byte aligned");
     const NgsCamera cam = make_camera(width, height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos);
     const GeomLayout gl = ngs_geom_layout((size_t)P);
     const BinLayout bl = ngs_bin_layout((size_t)R);

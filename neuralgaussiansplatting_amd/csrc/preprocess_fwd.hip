@@ -150,9 +150,10 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 6; k++) c6[k] = cov_pre[6 * (size_t)idx + k];
             } else {
-                const float4 q = ((const float4*)rots)[idx];
-                cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], mod, q.x, q.y, q.z,
-                                     q.w, c6);
+                // element loads: this kernel also serves quaternion arrays that are not 16-byte aligned
+                const float* q = rots + 4 * (size_t)idx;
+                cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], mod, q[0], q[1], q[2],
+                                     q[3], c6);
             }
             const Cov2D k = cov2d_eval(px, py, pz, cam, view, c6);
             const float det = k.a * k.c - k.b * k.b;

@@ -663,6 +663,20 @@ static void sh_backward(int deg, int M, const float* mean, const float* campos, 
     d_mean_acc[2] += (-d0.x * d0.z * dl.x - d0.y * d0.z * dl.y + (sum2 - d0.z * d0.z) * dl.z) * inv32;
 }
 
+/*
+ * The SH stage of the backward pass on its own (dgr/cuda_rasterizer/backward.cu:20-139 as called from :390-391):
+ * d_sh [P][M][3] is written for coefficients below (D+1)^2, d_means [P][3] receives (+=) the share that reaches
+ * the position through the view direction.  Exists so that this stage can be compared with gradients the
+ * reference's Python eval_sh yields under autograd.
+ */
+void ngs_oracle_sh_backward(int P, int D, int M, const float* means, const float* campos, const float* shs,
+                            const uint8_t* clamped, const float* d_col, float* d_means, float* d_sh)
+{
+    for (int i = 0; i < P; i++)
+        sh_backward(D, M, means + 3 * i, campos, shs + (size_t)3 * M * i, clamped + 3 * i, d_col + 3 * i,
+                    d_means + 3 * i, d_sh + (size_t)3 * M * i);
+}
+
 /* dgr/cuda_rasterizer/backward.cu:278-341 */
 static void cov3d_backward(const float* s_in, float mod, const float* q, const float* dcov, float* d_scale,
                            float* d_rot)

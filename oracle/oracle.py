@@ -72,6 +72,18 @@ def sh_to_rgb(deg, means3D, campos, shs):
     return rgb, cl
 
 
+def sh_backward(deg, means3D, campos, shs, clamped, dL_dcolor):
+    """(dL_dsh [P,M,3], dL_dmeans [P,3]) of the SH stage of the backward pass alone."""
+    means3D, campos, shs, dL_dcolor = _f32(means3D), _f32(campos), _f32(shs), _f32(dL_dcolor)
+    clamped = np.ascontiguousarray(clamped, dtype=np.uint8)
+    P, M = shs.shape[0], shs.shape[1]
+    d_sh = np.zeros((P, M, 3), np.float32)
+    d_means = np.zeros((P, 3), np.float32)
+    lib().ngs_oracle_sh_backward(P, int(deg), M, _p(means3D), _p(campos), _p(shs), _p(clamped), _p(dL_dcolor),
+                                 _p(d_means), _p(d_sh))
+    return d_sh, d_means
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     means3D = _f32(means3D)
     P = means3D.shape[0]

@@ -6,7 +6,8 @@ not exist on the GPU box):  python tests/golden/make_golden.py
 The reference ships no tests or golden vectors for the rasterizer, and its
 CUDA sources cannot be built here, so these fixtures pin what its Python can
 pin: SH -> RGB (utils/sh_utils.py:57-112, the function behind the
-``convert_SHs_python`` switch, gaussian_renderer/__init__.py:74-79), the
+``convert_SHs_python`` switch, gaussian_renderer/__init__.py:74-79) and its
+gradients under autograd, the
 camera matrices (utils/graphics_utils.py:38-71 combined as in
 scene/cameras.py:54-57), the training loss terms (utils/loss_utils.py:17-63), the
 combined loss of train.py:90-92 with its gradient wrt the image, and the
@@ -41,6 +42,51 @@ def sh_fixture():
         out["rgb_deg%d" % deg] = torch.clamp_min(rgb + 0.5, 0.0).numpy()
         out["raw_deg%d" % deg] = (rgb + 0.5).numpy()
     np.savez(os.path.join(HERE, "sh_to_rgb.npz"), **out)
+
+
+def sh_backward_fixture():
+    """Gradients of the colour stage as the reference's ``convert_SHs_python`` branch computes them
+    (gaussian_renderer/__init__.py:74-79): eval_sh on the normalised view direction, +0.5, clamp at 0, all under
+    autograd, for a fixed dL/dcolour.  dL/dshs and dL/dmeans (through the direction's normalisation) are what the
+    rasterizer's SH backward must reproduce (cuda_rasterizer/backward.cu:20-139, auxiliary.h:107-117)."""
+    g = torch.Generator().manual_seed(4242)
+    P = 131
+    means0 = (torch.rand(P, 3, generator=g) * 2 - 1) * 1.5
+    campos = torch.tensor([0.25, -0.4, -3.0])
+    shs0 = torch.randn(P, 16, 3, generator=g) * 1.5  # large enough that some channels clamp
+    dL_dcolor = torch.randn(P, 3, generator=g)
+    out = {"means": means0.numpy(), "campos": campos.numpy(), "shs": shs0.numpy(), "dL_dcolor": dL_dcolor.numpy()}
+    for deg in range(4):
+        means = means0.clone().requires_grad_(True)
+        shs = shs0.clone().requires_grad_(True)
+        shs_view = shs.transpose(1, 2).view(-1, 3, 16)
+        dir_pp = means - campos.repeat(P, 1)
+        dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+        sh2rgb = eval_sh(deg, shs_view, dir_pp_normalized)
+        colors = torch.clamp_min(sh2rgb + 0.5, 0.0)
+        (colors * dL_dcolor).sum().backward()
+        out["raw_deg%d" % deg] = (sh2rgb + 0.5).detach().numpy()
+        out["dL_dshs_deg%d" % deg] = shs.grad.numpy()
+        # degree 0 does not look at the direction: autograd leaves no gradient on the positions
+        out["dL_dmeans_deg%d" % deg] = np.zeros((P, 3), np.float32) if means.grad is None else means.grad.numpy()
+        # The same map in factored form, so that a test can apply it to ANY colour gradient (the one a GPU run
+        # produces): d(colour before the clamp)/d(shs) is the basis value per coefficient, and
+        # jac[p, j, c] = d(colour c before the clamp of Gaussian p)/d(means[p, j]).
+        jac = np.zeros((P, 3, 3), np.float32)
+        basis = None
+        for ch in range(3):
+            m2 = means0.clone().requires_grad_(True)
+            s2 = shs0.clone().requires_grad_(True)
+            d2 = m2 - campos.repeat(P, 1)
+            raw = eval_sh(deg, s2.transpose(1, 2).view(-1, 3, 16), d2 / d2.norm(dim=1, keepdim=True))
+            raw[:, ch].sum().backward()
+            if m2.grad is not None:
+                jac[:, :, ch] = m2.grad.numpy()
+            if ch == 0:
+                basis = s2.grad[:, :, 0].numpy().copy()
+        out["jac_deg%d" % deg] = jac
+        out["basis_deg%d" % deg] = basis
+    np.savez(os.path.join(HERE, "sh_backward.npz"), **out)
 
 
 def camera_fixture():
@@ -100,6 +146,7 @@ def lr_fixture():
 
 if __name__ == "__main__":
     sh_fixture()
+    sh_backward_fixture()
     camera_fixture()
     loss_fixture()
     train_loss_fixture()

@@ -348,6 +348,119 @@ def test_config4_3m_1080p_full_size(dgr, oracle):
         oracle.set_threads(1)
 
 
+def test_config3_300k_800x800_sh3(dgr, oracle):
+    """BASELINE configuration 3 (300 k Gaussians, 800x800, SH degree 3; its training loop is covered by
+    test_train_step_gpu.py::test_training_iterations_match_pytorch_assembly[c3]) at full size."""
+    oracle.set_threads(8)
+    try:
+        from neuralgaussiansplatting_amd import synthetic
+        sc, W, H = synthetic.make_config("c3")
+        cam = synthetic.make_view(W, H, 0)
+        c = dict(scene=sc, cam=cam, W=W, H=H, D=3, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
+                 tanfovy=math.tan(cam.FoVy * 0.5))
+        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(15))
+        o = oracle_forward(oracle, c)
+        assert 2.0 < o["num_rendered"] / 300_000 < 8.0
+        h = run_hip(dgr, c, dL_dpix=dL)
+        edge = check_forward(o, h, exact_pixels=False)
+        oracle.set_threads(1)
+        og = oracle_backward(oracle, c, o, dL)
+        check_grads(h["grads"], og, scale=float(W * H), knife_edge_pixels=edge)
+    finally:
+        oracle.set_threads(1)
+
+
+@pytest.mark.parametrize("view", [0, 5])
+def test_config5_6m_1080p_one_view_per_gpu(view, dgr, oracle):
+    """BASELINE configuration 5 is 6 M Gaussians at 1080p with eight orbit views, one per GPU: this is what each
+    GPU computes, for two of the eight views, at full size (the exchange between GPUs is covered by
+    test_view_parallel_gloo.py and the two-rank tests of test_train_step_gpu.py)."""
+    import os
+    from neuralgaussiansplatting_amd import synthetic
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        sc, W, H = synthetic.make_config("c5", seed=1234)
+        cam = synthetic.make_view(W, H, view, count=8)
+        c = dict(scene=sc, cam=cam, W=W, H=H, D=3, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
+                 tanfovy=math.tan(cam.FoVy * 0.5))
+        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(20 + view))
+        o = oracle_forward(oracle, c)
+        h = run_hip(dgr, c, dL_dpix=dL)
+        assert h["R"] == o["num_rendered"] > 12_000_000
+        edge = check_forward(o, h, exact_pixels=False)
+        assert int(h["tiles_touched"].sum()) == h["R"]
+        og = oracle_backward(oracle, c, o, dL)
+        check_grads(h["grads"], og, scale=float(W * H), knife_edge_pixels=edge)
+    finally:
+        oracle.set_threads(1)
+
+
+def test_closed_form_three_gaussian_scene(dgr):
+    """Image and gradients against a float64 closed form computed from first principles (pinhole projection, EWA
+    covariance, alpha blending, finite differences) -- tests/analytic_scene.py -- which shares no code or formula
+    sheet with the CPU checker."""
+    import analytic_scene as A
+    c = A.as_case()
+    h = run_hip(dgr, c, dL_dpix=torch.tensor(A.loss_weights(), dtype=torch.float32))
+    assert (h["radii"] > 0).all()
+    A.check_against_closed_form(h["color"], h["grads"])
+
+
+@pytest.mark.parametrize("deg", range(4))
+def test_kernel_sh_backward_matches_reference_autograd_fixture(deg, dgr):
+    """The SH stage of the backward kernel against gradients the reference's Python eval_sh gave under autograd
+    (tests/golden/sh_backward.npz, made by tests/golden/make_golden.py from utils/sh_utils.py:57-112 as called at
+    gaussian_renderer/__init__.py:74-79).  The fixture holds the map in factored form -- basis values per
+    coefficient and the Jacobian of the colour wrt the position -- so it applies to the colour gradient this run's
+    compositing stage produces:
+      dL_dsh[k][c]      = basis[k] * masked dL_dcolor[c]
+      dL_dmeans (SH share) = jac @ masked dL_dcolor
+    The SH share of dL_dmeans3D is isolated as the difference between a run through the SH path and a run with the
+    same colours precomputed (which has every other share and no SH share)."""
+    import os
+    from neuralgaussiansplatting_amd.cameras import make_camera
+    from neuralgaussiansplatting_amd import synthetic
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sh_backward.npz"))
+    dev = torch.device("cuda:0")
+    P = z["means"].shape[0]
+    W = H = 128
+    cam = make_camera(W, H, synthetic.FOVX, tuple(float(v) for v in z["campos"]))
+    sc = synthetic.Scene(torch.tensor(z["means"]), torch.tensor(z["shs"]), torch.full((P, 1), 0.6),
+                         torch.full((P, 3), 0.05), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1), deg)
+    c = dict(scene=sc, cam=cam, W=W, H=H, D=deg, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
+             tanfovy=math.tan(cam.FoVy * 0.5))
+    # the fixture's camera position, bit for bit, is what the direction is measured from
+    cam.camera_center = torch.tensor(z["campos"])
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(deg))
+    a = run_hip(dgr, c, dL_dpix=dL)
+    vis = a["radii"] > 0
+    assert vis.sum() > P // 2
+    raw = z["raw_deg%d" % deg]
+    decided = (np.abs(raw) > 1e-5).all(axis=1)
+    use = vis & decided
+    mask = (raw >= 0).astype(np.float32)
+    bits = ((raw[:, 0] < 0) | ((raw[:, 1] < 0) << 1) | ((raw[:, 2] < 0) << 2)).astype(np.uint8)
+    np.testing.assert_array_equal(a["clamped_bits"][use], bits[use])
+    masked = a["grads"]["dL_dcolors"] * mask
+    assert float(np.abs(masked[use]).max()) > 0.1
+    # coefficient gradients
+    want_sh = z["basis_deg%d" % deg][:, :, None] * masked[:, None, :]
+    got_sh = a["grads"]["dL_dsh"].reshape(P, 16, 3)
+    np.testing.assert_allclose(got_sh[use], want_sh[use], rtol=0, atol=2e-6 * float(np.abs(want_sh[use]).max()))
+    # share of the position gradient that flows through the view direction
+    b = run_hip(dgr, c, dL_dpix=dL, colors_precomp=torch.tensor(a["rgb"]))
+    np.testing.assert_allclose(b["color"], a["color"], rtol=0, atol=1e-6)
+    got_dir = a["grads"]["dL_dmeans3D"] - b["grads"]["dL_dmeans3D"]
+    want_dir = np.einsum("pjc,pc->pj", z["jac_deg%d" % deg], masked)
+    noise = 4e-6 * float(np.abs(a["grads"]["dL_dmeans3D"]).max())  # two float32 sums of atomics are subtracted
+    np.testing.assert_allclose(got_dir[use], want_dir[use], rtol=0,
+                               atol=noise + 2e-6 * float(np.abs(want_dir[use]).max()))
+    if deg == 0:
+        assert not want_dir.any()
+    else:
+        assert float(np.abs(want_dir[use]).max()) > 1e-3
+
+
 def test_empty_scene(dgr):
     dev = torch.device("cuda:0")
     e = torch.empty(0)
@@ -368,6 +481,45 @@ def test_bad_means_shape_raises(dgr):
         dgr._C.rasterize_gaussians(torch.zeros(3, device=dev), torch.zeros(4, 2, device=dev), e, e, e, e, 1.0, e,
                                    torch.eye(4, device=dev), torch.eye(4, device=dev), 0.3, 0.3, 16, 16, e, 0,
                                    torch.zeros(3, device=dev), False, False)
+
+
+def test_backward_rejects_bad_degree_and_misaligned_quaternions(dgr):
+    """Direct callers of the C ABI: an SH degree that needs more coefficients than a row holds, and quaternion or
+    quaternion-gradient arrays that are not 16-byte aligned, are errors (not out-of-bounds or misaligned accesses)."""
+    import ctypes
+    dev = torch.device("cuda:0")
+    c = case(P=50, W=32, H=32, D=1, M=9, seed=3)
+    sc, cam = c["scene"], c["cam"]
+    g = lambda t: t.to(dev)
+    e = torch.empty(0)
+    means, shs, scales, bg = g(sc.means3D), g(sc.shs), g(sc.scales), g(c["bg"])
+    rots = g(sc.rotations)
+    vm, pm, cp = g(cam.world_view_transform), g(cam.full_proj_transform), g(cam.camera_center)
+    R, color, radii, geom, binning, img = dgr._C.rasterize_gaussians(
+        bg, means, e, g(sc.opacities), scales, rots, 1.0, e, vm, pm, c["tanfovx"], c["tanfovy"], 32, 32, shs, 1, cp,
+        False, False)
+    dL = torch.randn(3, 32, 32, generator=torch.Generator().manual_seed(1)).to(dev)
+    with pytest.raises(RuntimeError, match="SH degree"):
+        dgr._C.rasterize_gaussians_backward(bg, means, radii, e, scales, rots, 1.0, e, vm, pm, c["tanfovx"],
+                                            c["tanfovy"], dL, shs, 3, cp, geom, R, binning, img, False)
+    # misaligned quaternions (a slice that starts 4 bytes into an allocation)
+    flat = torch.zeros(4 * 50 + 1, device=dev)
+    flat[1:] = rots.reshape(-1)
+    shifted = flat[1:].view(50, 4)
+    assert shifted.data_ptr() % 16 == 4
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        dgr._C.rasterize_gaussians_backward(bg, means, radii, e, scales, shifted, 1.0, e, vm, pm, c["tanfovx"],
+                                            c["tanfovy"], dL, shs, 1, cp, geom, R, binning, img, False)
+    out = torch.zeros(4 * 50 + 1, device=dev)
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        dgr._C.rasterize_gaussians_backward(bg, means, radii, e, scales, rots, 1.0, e, vm, pm, c["tanfovx"],
+                                            c["tanfovy"], dL, shs, 1, cp, geom, R, binning, img, False,
+                                            out={"dL_drotations": out[1:]})
+    # the forward pass takes misaligned quaternions (element loads) and gives the same image
+    R2, color2, *_ = dgr._C.rasterize_gaussians(
+        bg, means, e, g(sc.opacities), scales, shifted, 1.0, e, vm, pm, c["tanfovx"], c["tanfovy"], 32, 32, shs, 1, cp,
+        False, False)
+    assert R2 == R and torch.equal(color2, color)
 
 
 def test_prefiltered_with_culled_point_is_an_error(dgr):

@@ -167,14 +167,20 @@ def test_fused_sh_adam_from_views_equals_gradient_then_adam(C):
     assert not torch.equal(p2, sh0)
 
 
-def test_training_iterations_match_pytorch_assembly(C):
+@pytest.mark.parametrize("config", ["small", "c3"])
+def test_training_iterations_match_pytorch_assembly(C, config):
     """Three iterations of GaussianTrainer against the same iterations assembled the reference's way: separate
     f_dc / f_rest parameters concatenated per iteration, activations and loss as PyTorch operators under autograd
-    around render(), torch.optim.Adam with the reference's parameter groups."""
+    around render(), torch.optim.Adam with the reference's parameter groups.  ``c3`` is BASELINE configuration 3
+    (300 k Gaussians, 800x800, SH degree 3, training loop) at full size."""
     from neuralgaussiansplatting_amd.gaussian_model import GaussianModel
     from neuralgaussiansplatting_amd.gaussian_renderer import PipelineParams, render
-    P, W, H, D = 4000, 160, 96, 3
-    sc = synthetic.make_scene(P, D, (-4.0, -3.0), (1.3, 1.3, 1.3), seed=3, sh_coeffs=16)
+    if config == "c3":
+        sc, W, H = synthetic.make_config("c3")
+        P, D = sc.means3D.shape[0], 3
+    else:
+        P, W, H, D = 4000, 160, 96, 3
+        sc = synthetic.make_scene(P, D, (-4.0, -3.0), (1.3, 1.3, 1.3), seed=3, sh_coeffs=16)
     cams = [make_camera(W, H, synthetic.FOVX, e, device=DEV) for e in ((0.7, 0.5, -4.0), (-2.0, 0.4, -3.4), (1.5, -0.3, -3.6))]
     gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(40 + i)).to(DEV) for i in range(3)]
     bg = torch.zeros(3, device=DEV)
@@ -199,7 +205,16 @@ def test_training_iterations_match_pytorch_assembly(C):
         loss.backward()
         opt.step()
         assert abs(float(terms[2]) - loss.item()) < 1e-5
-        assert float((color - pkg["render"].detach()).abs().max()) < 1e-4
+        # A splat may sit on the other side of the 1/255 alpha threshold in a few pixels of a large image: in the
+        # first iteration (identical parameters, exp differing by an ulp) at most two pixels per 100 000 may differ
+        # by more than 1e-4; later the two sides have taken slightly different Adam steps (see below: a rounding-
+        # level gradient may step either way by a whole learning rate, for up to 0.5 % of the elements), which
+        # moves more pixels across -- up to five in 10 000 -- but none by more than one faint splat's
+        # contribution, and the images stay equal on average to float32 rounding.
+        diff = (color - pkg["render"].detach()).abs().amax(dim=0)
+        few = 0 if config == "small" else int((2e-5 if it == 1 else 5e-4) * W * H)
+        assert int((diff >= 1e-4).sum()) <= few
+        assert float(diff.max()) < 2.0 / 255.0 and float(diff.mean()) < 1e-6
     got = dict(xyz=tr.xyz, f=tr.features, op=tr.opacity_raw, scl=tr.scaling_raw, rot=tr.rotation_raw)
     want = dict(xyz=xyz.detach(), f=torch.cat((f_dc, f_rest), dim=1).detach(), op=op.detach(), scl=scl.detach(),
                 rot=rot.detach())

@@ -9,9 +9,13 @@ checker's forward state and treated as constants, exactly as the reference's
 backward pass treats them (backward.cu:486-501).  Two reference conventions are
 reproduced on purpose: the 0.99 alpha cap is not differentiated
 (backward.cu:499,538: the gradient flows as if unclamped), and quaternions are
-used un-normalised (forward.cu:127).  Test scenes keep every Gaussian inside the
-1.3x frustum guard band, where the reference's clamp handling (backward.cu:175-176)
-and true differentiation coincide.
+used un-normalised (forward.cu:127).  A third convention concerns Gaussians
+outside the 1.3x frustum guard band: the forward pass replaces the view-space
+x (y) that enters the projection Jacobian by the clamped value
+(forward.cu:80-85), and the backward pass treats that value as a constant --
+no gradient reaches the position through it, neither via x nor via z
+(backward.cu:175-176,262-264).  ``clamp_like_reference`` states exactly that
+with a detach; inside the band it is the identity.
 """
 import torch
 
@@ -47,6 +51,15 @@ def rotation_unnormalised(q):
     return torch.stack(rows, dim=1).view(-1, 3, 3)
 
 
+def clamp_like_reference(t, tz, lim):
+    """View-space x (or y) as the projection Jacobian sees it: unchanged inside the guard band, the band's edge
+    times z -- as a constant -- outside it."""
+    ratio = t / tz
+    outside = (ratio < -lim) | (ratio > lim)
+    edge = (torch.clamp(ratio, -lim, lim) * tz).detach()
+    return torch.where(outside, edge, t)
+
+
 def render(means3D, ndc_offset, shs, opacities, scales, rotations, view_t, full_t, campos, bg, W, H, tanx, tany, deg,
            state, scale_modifier=1.0):
     """-> image [3,H,W] (float64).  ``state`` is the checker's forward dict (lists, ranges, n_contrib).
@@ -67,8 +80,8 @@ def render(means3D, ndc_offset, shs, opacities, scales, rotations, view_t, full_
     Sigma = L @ L.transpose(1, 2)
     fx, fy = W / (2.0 * tanx), H / (2.0 * tany)
     tz = p_view[:, 2]
-    tx = torch.clamp(p_view[:, 0] / tz, -1.3 * tanx, 1.3 * tanx) * tz
-    ty = torch.clamp(p_view[:, 1] / tz, -1.3 * tany, 1.3 * tany) * tz
+    tx = clamp_like_reference(p_view[:, 0], tz, 1.3 * tanx)
+    ty = clamp_like_reference(p_view[:, 1], tz, 1.3 * tany)
     zero = torch.zeros_like(tz)
     J = torch.stack([torch.stack([fx / tz, zero, -(fx * tx) / (tz * tz)], dim=1),
                      torch.stack([zero, fy / tz, -(fy * ty) / (tz * tz)], dim=1)], dim=1)  # [P,2,3]
