@@ -53,7 +53,7 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
         "duplicate_with_keys": 4 * P + 8 * vP + 8 * R,
         "radix_sort_tile_bits": tile_passes * 16 * R,
         "tile_ranges": 4 * R + 16 * T,
-        "segment_sort_depth": 4 * R + 4 * R + 12 * R + 8 * T,
+        "segment_sort_depth": 4 * R + 4 * R + 4 * R + 8 * T,  # list in, depth gather, list out
         "render_fwd": 40 * R + 8 * T + 20 * W * H,
         "zero_accumulator": 64 * P,
         "render_bwd": 112 * R + 8 * T + 20 * W * H,

@@ -60,10 +60,34 @@ int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_a
                           int* num_rendered);
 
 /*
+ * ngs_rasterize_forward with the binning buffer sized BEFORE the instance count is known, so that the host never
+ * has to wait for the count in the middle of the call (the reference does, rasterizer_impl.cu:280-285, and so does
+ * ngs_rasterize_forward: the GPU idles there while the count travels to the host and the next kernels travel back).
+ * No counterpart in the reference.  Arguments as ngs_rasterize_forward, plus binning_capacity = the number of
+ * (Gaussian, tile) instances the binning buffer shall hold: the binning allocator is asked for
+ * ngs_required_binning_bytes(binning_capacity) right away and every stage is queued at once; the kernels take the
+ * count from device memory.  The host reads the count only after the last stage has been queued (for the return
+ * value, and to compare it with the capacity).  If the scene produces MORE instances than the capacity, the stages
+ * after the count are queued a second time with a buffer of the right size (one more call of the binning
+ * allocator): the results are the same, the call is slower.  A good capacity is the previous call's count plus a
+ * few percent.  binning_capacity == 0 is ngs_rasterize_forward.
+ */
+int ngs_rasterize_forward_presized(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
+                                   void* binning_ctx, ngs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                                   const float* background, int width, int height, const float* means3D,
+                                   const float* shs, const float* colors_precomp, const float* opacities,
+                                   const float* scales, float scale_modifier, const float* rotations,
+                                   const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                   const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                                   float* out_color, int* radii, int debug, void* stream, int* num_rendered,
+                                   long long binning_capacity);
+
+/*
  * Rasterizer::backward (rasterizer.h:55-84, rasterizer_impl.cu:340-434).
  * geom_buffer / binning_buffer / image_buffer are the buffers the forward call
  * filled (or copies of them at addresses with the same residue modulo 256;
- * they are re-carved from P, R and the image size).  Every output element is WRITTEN (zeros for culled Gaussians), so
+ * they are re-carved from P and the image size; of the binning buffer only the
+ * first 4 * R bytes past the 256-byte boundary, the sorted point list, are read).  Every output element is WRITTEN (zeros for culled Gaussians), so
  * the caller need not zero-fill; dL_dconic ([P][2][2]) may be NULL, and so may dL_dsh (the SH coefficient gradient
  * is then not produced; its share of dL_dmean3D still is -- see ngs_sh_gradient_from_views).
  * rotations, dL_drot and dL_dconic must be 16-byte aligned (an error otherwise); D and M as in the forward call.
@@ -127,7 +151,8 @@ int ngs_mark_visible(int P, const float* means3D, const float* viewmatrix, const
                      unsigned char* present, void* stream);
 
 /* Bytes the allocators will be asked for: the counterpart of
- * required<GeometryState / BinningState / ImageState>() (rasterizer_impl.h:67-73). */
+ * required<GeometryState / BinningState / ImageState>() (rasterizer_impl.h:67-73).  R is the instance count, or
+ * the capacity given to ngs_rasterize_forward_presized. */
 size_t ngs_required_geometry_bytes(int P);
 size_t ngs_required_binning_bytes(long long R);
 size_t ngs_required_image_bytes(int width, int height);
@@ -270,7 +295,9 @@ int ngs_knn_mean_dist2(int P, const float* points, float* mean_dist2, char* work
  *                depth(float), tile_rect(uint2 packed lo|hi<<16), tiles_touched(u32),
  *                internal_radii(i32), clamped_bits(u8), block_sums(u32),
  *                block_offsets(u32), misc(u32[8]), grad_accumulator(float[16])
- *  binning[2]:   sorted_keys(u64), point_list(u32)   (the unsorted pairs do not survive the sort's ping-pong)
+ *  binning[1]:   point_list(u32), always 0.  The sorted 64-bit keys (tile << 32 | depth bits) of the reference's
+ *                BinningState are not stored: nothing reads them after the sort; entry i of the point list lies in
+ *                the tile whose range holds i, and its depth bits are depth[point_list[i]]
  *  image[3]:     final_T(float, per tile in thread order: [tile][2x2 blocks][2x2 quadrants][4][4]), n_contrib(u32, tile-major), ranges(uint2[tiles])
  * No counterpart in the reference (its state structs are private, rasterizer_impl.h:29-65).
  */

@@ -121,11 +121,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
 // contiguous run of the output; the wave walks that run 64 entries at a time,
 // each lane locating its Gaussian by binary search over the wave's prefix sums,
 // so key/value stores are fully coalesced whatever the footprint sizes are.
+// Instances beyond `capacity` (a binning buffer sized from an estimate that turned out too small) are dropped and
+// flagged in misc[1]; the host then runs the stages again with a buffer that fits.
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const uint2* __restrict__ rect,
                                                                     const uint32_t* __restrict__ tiles,
                                                                     const uint32_t* __restrict__ block_offs,
                                                                     int grid_x, uint32_t* __restrict__ keys,
-                                                                    uint32_t* __restrict__ vals)
+                                                                    uint32_t* __restrict__ vals, uint32_t capacity,
+                                                                    uint32_t* __restrict__ misc)
 {
     __shared__ uint32_t s_incl[NGS_GAUSS_BLOCK];  // per wave: inclusive prefix of tiles within the wave
     __shared__ uint2 s_rect[NGS_GAUSS_BLOCK];
@@ -143,7 +146,11 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
     __syncthreads();
     uint32_t wave_base = block_offs[blockIdx.x];
     for (int w = 0; w < wave; w++) wave_base += s_wave_tot[w];
-    const uint32_t wave_total = s_wave_tot[wave];
+    uint32_t wave_total = s_wave_tot[wave];
+    if (wave_base + wave_total > capacity || wave_base + wave_total < wave_base) {  // wave-uniform
+        if (lane == 0 && wave_total != 0) atomicOr(&misc[1], 4u);
+        wave_total = wave_base < capacity ? capacity - wave_base : 0u;
+    }
     const uint32_t* incl_w = s_incl + wave * 64;
     for (uint32_t k = lane; k < wave_total; k += 64) {
         // smallest j with incl_w[j] > k
@@ -163,10 +170,12 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
     }
 }
 
-// rasterizer_impl.cu:116-138; `ranges` was zeroed by the caller.
-__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t L, const uint32_t* __restrict__ keys,
+// rasterizer_impl.cu:116-138; `ranges` was zeroed by the caller.  L = min(*count, capacity).
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ count, int64_t capacity,
+                                                          const uint32_t* __restrict__ keys,
                                                           uint2* __restrict__ ranges)
 {
+    const int64_t L = min((int64_t)*count, capacity);
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
     const uint32_t cur = keys[idx];
@@ -183,9 +192,11 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t L, const uint3
 }
 
 // The same with four keys per thread (one 16-byte load plus the key before them).
-__global__ __launch_bounds__(256) void tile_ranges_vec_kernel(int64_t L, const uint32_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void tile_ranges_vec_kernel(const uint32_t* __restrict__ count, int64_t capacity,
+                                                              const uint32_t* __restrict__ keys,
                                                               uint2* __restrict__ ranges)
 {
+    const int64_t L = min((int64_t)*count, capacity);
     const int64_t first = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (first >= L) return;
     uint32_t k[4];
@@ -221,18 +232,21 @@ void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* bloc
 }
 
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
-                          int grid_x, uint32_t* keys, uint32_t* vals)
+                          int grid_x, uint32_t* keys, uint32_t* vals, int64_t capacity, uint32_t* misc)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
     hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, rect, tiles, block_offs, grid_x,
-                       keys, vals);
+                       keys, vals, (uint32_t)capacity, misc);
 }
 
-void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint32_t* keys, int T, uint2* ranges)
+void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* keys, int T,
+                            uint2* ranges)
 {
     (void)hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s);
-    if (R > 0 && (uintptr_t)keys % 16 == 0)
-        hipLaunchKernelGGL(tile_ranges_vec_kernel, dim3((unsigned)((R + 1023) / 1024)), dim3(256), 0, s, R, keys, ranges);
-    else if (R > 0)
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);
+    if (capacity > 0 && (uintptr_t)keys % 16 == 0)
+        hipLaunchKernelGGL(tile_ranges_vec_kernel, dim3((unsigned)((capacity + 1023) / 1024)), dim3(256), 0, s, count,
+                           capacity, keys, ranges);
+    else if (capacity > 0)
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, s, count,
+                           capacity, keys, ranges);
 }

@@ -242,11 +242,7 @@ extern "C" int ngs_state_layout(int P, long long R, int W, int H, size_t* geomet
                               g.misc, g.acc};
         memcpy(geometry, v, sizeof v);
     }
-    if (binning) {
-        const BinLayout b = ngs_bin_layout((size_t)R);
-        binning[0] = b.keys[0];
-        binning[1] = b.vals[0];
-    }
+    if (binning) binning[0] = ngs_bin_layout((size_t)R).vals[0];
     if (image) {
         const ImageLayout i = ngs_image_layout(W, H);
         image[0] = i.final_T; image[1] = i.n_contrib; image[2] = i.ranges;
@@ -254,37 +250,37 @@ extern "C" int ngs_state_layout(int P, long long R, int W, int H, size_t* geomet
     return 0;
 }
 
-extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
-                                     void* binning_ctx, ngs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
-                                     const float* background, int width, int height, const float* means3D,
-                                     const float* shs, const float* colors_precomp, const float* opacities,
-                                     const float* scales, float scale_modifier, const float* rotations,
-                                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                                     const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-                                     float* out_color, int* radii, int debug, void* stream, int* num_rendered)
+static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
+                        void* binning_ctx, ngs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                        const float* background, int width, int height, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales,
+                        float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                        float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
+                        int* num_rendered, long long binning_capacity)
 {
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
     if (num_rendered) *num_rendered = 0;
-    if (P < 0 || P > NGS_MAX_GAUSSIANS || width <= 0 || height <= 0) return fail("ngs_rasterize_forward", "bad sizes");
+    if (P < 0 || P > NGS_MAX_GAUSSIANS || width <= 0 || height <= 0 || binning_capacity < 0) return fail(fn, "bad sizes");
     if (P == 0) return 0;
-    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail("ngs_rasterize_forward", "missing allocator");
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(fn, "missing allocator");
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !background || !out_color)
-        return fail("ngs_rasterize_forward", "missing required pointer");
-    if (!colors_precomp && (!shs || !cam_pos)) return fail("ngs_rasterize_forward", "need shs+cam_pos or colors_precomp");
+        return fail(fn, "missing required pointer");
+    if (!colors_precomp && (!shs || !cam_pos)) return fail(fn, "need shs+cam_pos or colors_precomp");
     if (!colors_precomp && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
-        return fail("ngs_rasterize_forward", "SH degree does not fit the coefficient count");
-    if (!cov3D_precomp && (!scales || !rotations)) return fail("ngs_rasterize_forward", "need scales+rotations or cov3D_precomp");
+        return fail(fn, "SH degree does not fit the coefficient count");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(fn, "need scales+rotations or cov3D_precomp");
     const NgsCamera cam = make_camera(width, height, tan_fovx, tan_fovy, viewmatrix, projmatrix, cam_pos);
-    if (cam.grid_x > 65535 || cam.grid_y > 65535) return fail("ngs_rasterize_forward", "image too large");
+    if (cam.grid_x > 65535 || cam.grid_y > 65535) return fail(fn, "image too large");
 
     const GeomLayout gl = ngs_geom_layout((size_t)P);
     char* gb = geometry_alloc(geometry_ctx, gl.total);
-    if (!gb) return fail("ngs_rasterize_forward", "geometry allocator returned NULL");
+    if (!gb) return fail(fn, "geometry allocator returned NULL");
     gb = ngs_align_ptr(gb);
     const ImageLayout il = ngs_image_layout(width, height);
     char* ib = image_alloc(image_ctx, il.total);
-    if (!ib) return fail("ngs_rasterize_forward", "image allocator returned NULL");
+    if (!ib) return fail(fn, "image allocator returned NULL");
     ib = ngs_align_ptr(ib);
 
     float4* rec = (float4*)(gb + gl.rec);
@@ -313,61 +309,110 @@ extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry
     prof_end(ps, ST_SCAN, st);
     NGS_STAGE("scan");
 
-    // The instance count sizes the binning buffer, so the host has to wait for it here (the reference blocks on a
-    // device-to-host copy at the same point, rasterizer_impl.cu:281).  The scan kernel posts the 8 bytes straight
-    // into pinned host memory and the host spins on them; if they do not arrive (a failed kernel, a platform
-    // without coherent host memory) the wait falls back to a copy and a stream synchronisation.
+    // The host needs the instance count: to size the binning buffer when the caller gave no capacity (the reference
+    // blocks on a device-to-host copy at the same point, rasterizer_impl.cu:281), and for the return value either
+    // way.  The scan kernel posts the 8 bytes (count, error flags) straight into pinned host memory and the host
+    // spins on them; if they do not arrive (a failed kernel, a platform without coherent host memory) the wait
+    // falls back to a copy and a stream synchronisation.  With a capacity the wait comes AFTER every stage has been
+    // queued, so the GPU never idles while the host learns the count.
     uint32_t host_misc[2] = {0, 0};
-    if (!mailbox_wait(mb, st, host_misc)) {
-        NGS_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, st));
-        NGS_HIP(hipStreamSynchronize(st));
+    bool count_known = false;
+    auto learn_count = [&]() -> int {
+        if (!mailbox_wait(mb, st, host_misc)) {
+            NGS_HIP(hipMemcpyAsync(host_misc, misc, sizeof host_misc, hipMemcpyDeviceToHost, st));
+            NGS_HIP(hipStreamSynchronize(st));
+        }
+        count_known = true;
+        if (host_misc[1] & 1u) return fail(fn, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        if ((host_misc[1] & 2u) || host_misc[0] > 0x7fffffffu) return fail(fn, "more than 2^31-1 tile instances");
+        return 0;
+    };
+    int64_t capacity = binning_capacity > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)binning_capacity;
+    if (capacity == 0) {
+        if (learn_count()) return 1;
+        capacity = (int64_t)host_misc[0];
     }
-    if (host_misc[1] & 1u) return fail("ngs_rasterize_forward", "Point is filtered although prefiltered is set. This shouldn't happen!");
-    if ((host_misc[1] & 2u) || host_misc[0] > 0x7fffffffu) return fail("ngs_rasterize_forward", "more than 2^31-1 tile instances");
-    const int64_t R = (int64_t)host_misc[0];
-    if (num_rendered) *num_rendered = (int)R;
-
-    const BinLayout bl = ngs_bin_layout((size_t)R);
-    char* bb = binning_alloc(binning_ctx, bl.total);
-    if (!bb) return fail("ngs_rasterize_forward", "binning allocator returned NULL");
-    bb = ngs_align_ptr(bb);
-    uint64_t* const keys64 = (uint64_t*)(bb + bl.keys[0]);       // sorted (tile << 32 | depth) keys, written last
-    uint64_t* const spare64 = (uint64_t*)(bb + bl.keys[1]);      // tile-id ping/pong, then spare of the long sort
-    uint32_t* tkeys[2] = {(uint32_t*)spare64, (uint32_t*)spare64 + R};
-    uint32_t* vals[2] = {(uint32_t*)(bb + bl.vals[0]), (uint32_t*)(bb + bl.vals[1])};
-    uint32_t* hist = (uint32_t*)(bb + bl.hist);
-    uint32_t* totals = (uint32_t*)(bb + bl.totals);
 
     const int T = cam.grid_x * cam.grid_y;
     const int tile_bits = (int)higher_msb((uint32_t)T);
     const int in_buf = ngs_sort_input_buffer(tile_bits);
-    if (R > 0) {
-        prof_begin(ps, ST_DUPLICATE, st);
-        ngs_launch_duplicate(st, P, rect, tiles, block_offs, cam.grid_x, tkeys[in_buf], vals[in_buf]);
-        prof_end(ps, ST_DUPLICATE, st);
-        NGS_STAGE("duplicateWithKeys");
-        prof_begin(ps, ST_SORT, st);
-        ngs_launch_sort_tile_bits(st, R, tkeys, vals, hist, totals, tile_bits);
-        prof_end(ps, ST_SORT, st);
-        NGS_STAGE("sort");
-    }
     uint2* ranges = (uint2*)(ib + il.ranges);
-    prof_begin(ps, ST_RANGES, st);
-    ngs_launch_tile_ranges(st, R, tkeys[0], T, ranges);
-    prof_end(ps, ST_RANGES, st);
-    NGS_STAGE("identifyTileRanges");
-    if (R > 0) {
-        prof_begin(ps, ST_SEGSORT, st);
-        ngs_launch_sort_segments(st, T, ranges, depth, keys64, spare64, vals);
-        prof_end(ps, ST_SEGSORT, st);
-        NGS_STAGE("sort (depth)");
+    for (;;) {
+        const BinLayout bl = ngs_bin_layout((size_t)capacity);
+        char* bb = binning_alloc(binning_ctx, bl.total);
+        if (!bb) return fail(fn, "binning allocator returned NULL");
+        bb = ngs_align_ptr(bb);
+        uint32_t* tkeys[2] = {(uint32_t*)(bb + bl.keys[0]), (uint32_t*)(bb + bl.keys[1])};
+        uint32_t* vals[2] = {(uint32_t*)(bb + bl.vals[0]), (uint32_t*)(bb + bl.vals[1])};
+        uint32_t* hist = (uint32_t*)(bb + bl.hist);
+        uint32_t* totals = (uint32_t*)(bb + bl.totals);
+        if (capacity > 0) {
+            prof_begin(ps, ST_DUPLICATE, st);
+            ngs_launch_duplicate(st, P, rect, tiles, block_offs, cam.grid_x, tkeys[in_buf], vals[in_buf], capacity, misc);
+            prof_end(ps, ST_DUPLICATE, st);
+            NGS_STAGE("duplicateWithKeys");
+            prof_begin(ps, ST_SORT, st);
+            ngs_launch_sort_tile_bits(st, misc, capacity, tkeys, vals, hist, totals, tile_bits);
+            prof_end(ps, ST_SORT, st);
+            NGS_STAGE("sort");
+        }
+        prof_begin(ps, ST_RANGES, st);
+        ngs_launch_tile_ranges(st, misc, capacity, tkeys[0], T, ranges);
+        prof_end(ps, ST_RANGES, st);
+        NGS_STAGE("identifyTileRanges");
+        if (capacity > 0) {
+            prof_begin(ps, ST_SEGSORT, st);
+            ngs_launch_sort_segments(st, T, ranges, depth, tkeys, vals);
+            prof_end(ps, ST_SEGSORT, st);
+            NGS_STAGE("sort (depth)");
+        }
+        prof_begin(ps, ST_RENDER_FWD, st);
+        ngs_launch_render_fwd(st, cam, ranges, vals[0], rec, background, (float*)(ib + il.final_T),
+                              (uint32_t*)(ib + il.n_contrib), out_color);
+        prof_end(ps, ST_RENDER_FWD, st);
+        NGS_STAGE("render");
+        if (count_known) break;
+        if (learn_count()) return 1;
+        if ((int64_t)host_misc[0] <= capacity) break;
+        // The estimate was too small: the stages above worked on a truncated list (inside the buffer, so harmlessly).
+        // Queue them again with a buffer that holds every instance.
+        capacity = (int64_t)host_misc[0];
     }
-    prof_begin(ps, ST_RENDER_FWD, st);
-    ngs_launch_render_fwd(st, cam, ranges, vals[0], rec, background, (float*)(ib + il.final_T),
-                          (uint32_t*)(ib + il.n_contrib), out_color);
-    prof_end(ps, ST_RENDER_FWD, st);
-    NGS_STAGE("render");
+    if (num_rendered) *num_rendered = (int)host_misc[0];
     return 0;
+}
+
+extern "C" int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
+                                     void* binning_ctx, ngs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                                     const float* background, int width, int height, const float* means3D,
+                                     const float* shs, const float* colors_precomp, const float* opacities,
+                                     const float* scales, float scale_modifier, const float* rotations,
+                                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                     const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                                     float* out_color, int* radii, int debug, void* stream, int* num_rendered)
+{
+    return forward_impl("ngs_rasterize_forward", geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc,
+                        image_ctx, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales,
+                        scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+                        prefiltered, out_color, radii, debug, stream, num_rendered, 0);
+}
+
+extern "C" int ngs_rasterize_forward_presized(ngs_alloc_fn geometry_alloc, void* geometry_ctx,
+                                              ngs_alloc_fn binning_alloc, void* binning_ctx, ngs_alloc_fn image_alloc,
+                                              void* image_ctx, int P, int D, int M, const float* background, int width,
+                                              int height, const float* means3D, const float* shs,
+                                              const float* colors_precomp, const float* opacities, const float* scales,
+                                              float scale_modifier, const float* rotations,
+                                              const float* cov3D_precomp, const float* viewmatrix,
+                                              const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                              float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
+                                              void* stream, int* num_rendered, long long binning_capacity)
+{
+    return forward_impl("ngs_rasterize_forward_presized", geometry_alloc, geometry_ctx, binning_alloc, binning_ctx,
+                        image_alloc, image_ctx, P, D, M, background, width, height, means3D, shs, colors_precomp,
+                        opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
+                        tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, stream, num_rendered,
+                        binning_capacity);
 }
 
 // Optional hand-over between the two backward stages (ngs_rasterize_backward_early_color).
@@ -405,7 +450,7 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
         return fail(fn, "rotations, dL_drot and dL_dconic must be 16-byte aligned");
     const NgsCamera cam = make_camera(width, height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos);
     const GeomLayout gl = ngs_geom_layout((size_t)P);
-    const BinLayout bl = ngs_bin_layout((size_t)R);
+    const BinLayout bl = ngs_bin_layout((size_t)R);  // the point list sits at the same place for every capacity
     const ImageLayout il = ngs_image_layout(width, height);
     char* gb = ngs_align_ptr(geom_buffer);
     char* bb = ngs_align_ptr(binning_buffer);

@@ -324,7 +324,7 @@ void ngs_launch_knn(hipStream_t s, int P, const float* points, char* workspace, 
     (void)hipMemsetD32Async((hipDeviceptr_t)bounds, (int)0x80000000u, 6, s);  // encode(0.0f)
     hipLaunchKernelGGL(knn_bounds_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, s, P, points, bounds);
     hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, P, points, bounds, keys[in_buf], vals[in_buf]);
-    ngs_launch_sort_tile_bits(s, P, keys, vals, hist, totals, end_bit);  // stable: equal codes keep index order
+    ngs_launch_sort_tile_bits(s, nullptr, P, keys, vals, hist, totals, end_bit);  // stable: equal codes keep index order
     hipLaunchKernelGGL(knn_gather_kernel, dim3(nb), dim3(256), 0, s, P, points, vals[0], sorted, leaves);
     hipLaunchKernelGGL(knn_super_kernel, dim3(S), dim3(64), 0, s, L, leaves, supers);
     hipLaunchKernelGGL(knn_search_kernel, dim3((L + 3) / 4), dim3(256), 0, s, P, L, S, sorted, leaves, supers,

@@ -36,7 +36,8 @@ struct GeomLayout {
     size_t clamped;    // u8    [P]  bit ch set when colour channel ch was clamped at 0
     size_t block_sums; // u32   [ceil(P/256)] tiles touched per 256-Gaussian block
     size_t block_offs; // u32   [ceil(P/256)] exclusive prefix of block_sums
-    size_t misc;       // u32   [8]  [0] total instances R, [1] error flags
+    size_t misc;       // u32   [8]  [0] total instances R, [1] error flags (1 prefiltered point culled, 2 count
+                       //            beyond 2^31-1, 4 count beyond the binning buffer's capacity)
     size_t acc;        // float [P][16] gradient accumulator rows (backward)
     size_t total;
 };
@@ -48,11 +49,14 @@ struct ImageLayout {
     size_t total;
 };
 
+// Sized by a CAPACITY in instances (the count itself when the buffer is allocated after the count is known, an
+// estimate when it is allocated before).  The sorted point list comes first, so its address does not depend on
+// the capacity: that is all the backward pass needs from this buffer.
 struct BinLayout {
-    size_t keys[2];  // u64[R] each; keys[0] receives the sorted 64-bit keys, keys[1] holds the two u32[R] tile-id
-                     // arrays of the tile-level sort (then serves as the spare buffer of the long-segment sort)
-    size_t vals[2];  // u32[R] ping/pong; vals[0] is the sorted point list
-    size_t hist;     // u32[256 * sort_blocks] digit-major per-block histogram
+    size_t vals[2];  // u32[C] ping/pong; vals[0] (offset 0) is the sorted point list
+    size_t keys[2];  // u32[C] each: tile ids during the tile-level sort; afterwards the depth-key ping/pong of the
+                     // per-tile sort of long lists
+    size_t hist;     // u32[256 * sort_blocks(C)] digit-major per-block histogram
     size_t totals;   // u32[256] per-digit totals
     size_t total;
 };
@@ -93,14 +97,14 @@ static inline ImageLayout ngs_image_layout(int W, int H)
     return l;
 }
 
-static inline BinLayout ngs_bin_layout(size_t R)
+static inline BinLayout ngs_bin_layout(size_t C)
 {
     BinLayout l;
-    size_t o = 0, nb = (R + NGS_SORT_TILE - 1) / NGS_SORT_TILE;
-    l.keys[0] = o; o = ngs_align_up(o + R * 8);
-    l.keys[1] = o; o = ngs_align_up(o + R * 8);
-    l.vals[0] = o; o = ngs_align_up(o + R * 4);
-    l.vals[1] = o; o = ngs_align_up(o + R * 4);
+    size_t o = 0, nb = (C + NGS_SORT_TILE - 1) / NGS_SORT_TILE;
+    l.vals[0] = o; o = ngs_align_up(o + C * 4);
+    l.vals[1] = o; o = ngs_align_up(o + C * 4);
+    l.keys[0] = o; o = ngs_align_up(o + C * 4);
+    l.keys[1] = o; o = ngs_align_up(o + C * 4);
     l.hist = o; o = ngs_align_up(o + nb * 256 * 4);
     l.totals = o; o = ngs_align_up(o + 256 * 4);
     l.total = o + NGS_ALIGN;
@@ -177,18 +181,24 @@ void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const flo
 // or NULL.
 void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* block_sums, uint32_t* block_offs,
                                 uint32_t* misc, unsigned long long* mailbox);
+// The stages between the scan and the compositing take the instance count from DEVICE memory (`count`, the word
+// the scan kernel wrote) and a capacity: launches are sized by the capacity, kernels work on min(count, capacity)
+// instances, so they can be queued before the host knows the count and never step outside the buffer.
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
-                          int grid_x, uint32_t* tile_keys, uint32_t* vals);
-void ngs_launch_tile_ranges(hipStream_t s, int64_t R, const uint32_t* tile_keys, int T, uint2* ranges);
+                          int grid_x, uint32_t* tile_keys, uint32_t* vals, int64_t capacity, uint32_t* misc);
+void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* tile_keys, int T,
+                            uint2* ranges);
 // radix_sort.hip: stable sort of the instances on (tile, depth) in two levels: global radix passes over the low
 // `bits` bits of 32-bit keys (tile ids) carried with 32-bit values, result in keys[0]/vals[0]; then, once the tile
-// ranges are known, a per-tile sort on the depth of the listed Gaussians, which also writes the 64-bit keys.
+// ranges are known, a per-tile sort of vals[0] on the depth of the listed Gaussians (keys[] and vals[1] serve the
+// lists that do not fit a workgroup's registers as scratch).
 // ngs_sort_input_buffer returns the buffer index (0 or 1) the unsorted input must be written to.
+// `count` (device) may be NULL: the number of pairs is then `capacity` itself (the caller knows it).
 int ngs_sort_input_buffer(int bits);
-void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint32_t* const keys[2], uint32_t* const vals[2],
-                               uint32_t* hist, uint32_t* totals, int bits);
-void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint64_t* keys,
-                              uint64_t* spare_keys, uint32_t* const vals[2]);
+void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
+                               uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits);
+void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
+                              uint32_t* const vals[2]);
 // render_fwd.hip
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,

@@ -20,9 +20,17 @@
 //     gather from the per-Gaussian depth array, which stays in L2), sorts its
 //     segment by the 32 depth bits, stably, entirely in registers + LDS (four
 //     8-bit passes, passes whose digit is constant over the segment are
-//     skipped), and writes the 64-bit keys and the Gaussian list; segments
-//     longer than 4096 pairs run the same passes ping-ponging through global
-//     memory.
+//     skipped), and writes the Gaussian list back in place; segments longer
+//     than 4096 pairs run the same passes ping-ponging through global memory.
+//     The 64-bit keys themselves are never stored: nothing downstream reads
+//     them (the compositing kernels need the list and the tile ranges), and
+//     (tile << 32) | depth bits of each list entry can be re-derived from the
+//     ranges and the depth array whenever someone wants to look at them.
+//
+// The number of pairs comes from device memory (the instance count the scan
+// kernel wrote), capped by the capacity the buffers were sized for; launches
+// are sized by the capacity, so the passes can be queued before the host has
+// seen the count.
 //
 // Sorting stably by depth inside groups that are ordered by tile gives exactly
 // the order of a stable sort on (tile, depth).  The same level-1 passes sort
@@ -58,11 +66,22 @@ __device__ __forceinline__ uint32_t wave_rank(uint32_t d, bool valid, uint32_t* 
     return rank;
 }
 
-__global__ __launch_bounds__(ST) void sort_hist_kernel(int64_t n, const uint32_t* __restrict__ keys, int shift,
+__device__ __forceinline__ int64_t pair_count(const uint32_t* count, int64_t capacity)
+{
+    return count ? min((int64_t)*count, capacity) : capacity;
+}
+
+__global__ __launch_bounds__(ST) void sort_hist_kernel(const uint32_t* __restrict__ count, int64_t capacity,
+                                                       const uint32_t* __restrict__ keys, int shift,
                                                        uint32_t mask, int nblocks, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t s_cnt[SWAVES][256];
     const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t n = pair_count(count, capacity);
+    if ((int64_t)blockIdx.x * STILE >= n) {  // a block past the end (launches are sized by the capacity)
+        hist[(size_t)tid * nblocks + blockIdx.x] = 0;
+        return;
+    }
     for (int w = 0; w < SWAVES; w++) s_cnt[w][tid] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * STILE;
@@ -108,7 +127,8 @@ __global__ __launch_bounds__(SCAN_T) void sort_scan_kernel(int nblocks, uint32_t
     if (tid == 0) totals[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint32_t* __restrict__ kin,
+__global__ __launch_bounds__(ST) void sort_scatter_kernel(const uint32_t* __restrict__ count, int64_t capacity,
+                                                          const uint32_t* __restrict__ kin,
                                                           const uint32_t* __restrict__ vin,
                                                           uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                           int shift, uint32_t mask, int nblocks,
@@ -123,7 +143,9 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(int64_t n, const uint3
     __shared__ uint32_t s_key[STILE];
     __shared__ uint32_t s_val[STILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = pair_count(count, capacity);
     const int64_t base = (int64_t)blockIdx.x * STILE;
+    if (base >= n) return;  // block-uniform
     const int n_valid = (int)min((int64_t)STILE, n - base);
     for (int w = 0; w < SWAVES; w++) s_cnt[w][tid] = 0;
     __syncthreads();
@@ -246,7 +268,6 @@ __device__ __forceinline__ void block_rank_pass(const uint32_t (&key)[ITEMS], in
 template <int ITEMS, int THREADS>
 __global__ __launch_bounds__(THREADS) void segment_sort_small_kernel(const uint2* __restrict__ ranges, int min_n,
                                                                      const float* __restrict__ depth,
-                                                                     uint64_t* __restrict__ keys0,
                                                                      uint32_t* __restrict__ vals0)
 {
     constexpr int CAP = THREADS * ITEMS, WAVES = THREADS / 64;
@@ -257,10 +278,10 @@ __global__ __launch_bounds__(THREADS) void segment_sort_small_kernel(const uint2
     __shared__ uint32_t s_key[CAP];
     __shared__ uint32_t s_val[CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x;
-    const uint2 range = ranges[tile];
+    const uint2 range = ranges[blockIdx.x];
     const int n = (int)(range.y - range.x);
-    if (n <= min_n || n > CAP) return;  // block-uniform: another launch (or nobody, empty tile) owns this tile
+    // block-uniform: another launch (or nobody: an empty tile, or a single entry, which is sorted) owns this tile
+    if (n <= min_n || n > CAP || n < 2) return;
     const size_t lo = range.x;
     const int quota = ((((n + WAVES - 1) / WAVES) + 63) / 64) * 64;  // slots per wave
     uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
@@ -313,17 +334,15 @@ __global__ __launch_bounds__(THREADS) void segment_sort_small_kernel(const uint2
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int slot = wave * quota + i * 64 + lane;
-        if (i * 64 < quota && slot < n) {
-            keys0[lo + slot] = ((uint64_t)tile << 32) | key[i];
-            vals0[lo + slot] = val[i];
-        }
+        if (i * 64 < quota && slot < n) vals0[lo + slot] = val[i];
     }
 }
 
-// Segments longer than STILE pairs: the same four passes, chunk by chunk, ping-ponging through the spare buffer.
+// Segments longer than STILE pairs: the same four passes, chunk by chunk, ping-ponging through the spare buffers
+// (depth keys in keys0 / keys1, the list in vals0 / vals1; four passes end where they started, in vals0).
 __global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __restrict__ ranges,
-                                                               const float* __restrict__ depth, uint64_t* keys0,
-                                                               uint32_t* vals0, uint64_t* keys1, uint32_t* vals1)
+                                                               const float* __restrict__ depth, uint32_t* keys0,
+                                                               uint32_t* vals0, uint32_t* keys1, uint32_t* vals1)
 {
     __shared__ uint32_t s_cnt[SWAVES][256];
     __shared__ uint32_t s_start[256];
@@ -337,9 +356,9 @@ __global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __re
     const int quota = 64 * SI;
     for (int pass = 0; pass < 4; pass++) {
         const int shift = pass * 8;
-        const uint64_t* ksrc = (pass & 1) ? keys1 : keys0;
+        const uint32_t* ksrc = (pass & 1) ? keys1 : keys0;
         const uint32_t* vsrc = (pass & 1) ? vals1 : vals0;
-        uint64_t* kdst = (pass & 1) ? keys0 : keys1;
+        uint32_t* kdst = (pass & 1) ? keys0 : keys1;
         uint32_t* vdst = (pass & 1) ? vals0 : vals1;
         __syncthreads();  // the previous pass's stores are visible to the whole workgroup
         // digit histogram of the whole segment -> running digit bases
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __re
         __syncthreads();
         // the first pass has no keys yet: it builds them from the depth of each listed Gaussian
         for (int i = tid; i < n; i += ST) {
-            const uint32_t k = pass == 0 ? __float_as_uint(depth[vsrc[lo + i]]) : (uint32_t)ksrc[lo + i];
+            const uint32_t k = pass == 0 ? __float_as_uint(depth[vsrc[lo + i]]) : ksrc[lo + i];
             atomicAdd(&s_cnt[0][(k >> shift) & 0xffu], 1u);
         }
         __syncthreads();
@@ -369,7 +388,7 @@ __global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __re
                 const int slot = wave * quota + i * 64 + lane;
                 const bool valid = slot < m;
                 val[i] = valid ? vsrc[lo + c0 + slot] : 0u;
-                key[i] = !valid ? ~0u : pass == 0 ? __float_as_uint(depth[val[i]]) : (uint32_t)ksrc[lo + c0 + slot];
+                key[i] = !valid ? ~0u : pass == 0 ? __float_as_uint(depth[val[i]]) : ksrc[lo + c0 + slot];
             }
             uint32_t tot;
             block_rank_pass<SI>(key, shift, m, quota, s_cnt, s_start, s_wtot, pos, tot);
@@ -380,7 +399,7 @@ __global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __re
                 if (slot < m) {
                     const uint32_t d = (key[i] >> shift) & 0xffu;
                     const uint32_t g = s_base[d] + (pos[i] - s_start[d]);
-                    kdst[lo + g] = ((uint64_t)blockIdx.x << 32) | key[i];
+                    kdst[lo + g] = key[i];
                     vdst[lo + g] = val[i];
                 }
             }
@@ -395,11 +414,11 @@ static int tile_passes(int bits) { return (bits + 7) / 8; }
 
 int ngs_sort_input_buffer(int bits) { return tile_passes(bits) & 1; }
 
-void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint32_t* const keys[2], uint32_t* const vals[2],
-                               uint32_t* hist, uint32_t* totals, int bits)
+void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
+                               uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits)
 {
-    if (R <= 0) return;
-    const int nblocks = (int)((R + STILE - 1) / STILE);
+    if (capacity <= 0) return;
+    const int nblocks = (int)((capacity + STILE - 1) / STILE);
     int cur = ngs_sort_input_buffer(bits);
     // the bits are spread evenly over the passes (13 bits: 7 + 6, not 8 + 5): fewer buckets in a pass mean longer
     // runs per bucket in the scatter, i.e. fewer partially written memory lines
@@ -407,22 +426,23 @@ void ngs_launch_sort_tile_bits(hipStream_t s, int64_t R, uint32_t* const keys[2]
     for (int shift = 0, width; shift < bits; shift += width, passes_left--) {
         width = (bits - shift + passes_left - 1) / passes_left;
         const uint32_t mask = (1u << width) - 1u;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(ST), 0, s, R, keys[cur], shift, mask, nblocks, hist);
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur], shift, mask,
+                           nblocks, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(SCAN_T), 0, s, nblocks, hist, totals);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(ST), 0, s, R, keys[cur], vals[cur], keys[cur ^ 1],
-                           vals[cur ^ 1], shift, mask, nblocks, hist, totals);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur], vals[cur],
+                           keys[cur ^ 1], vals[cur ^ 1], shift, mask, nblocks, hist, totals);
         cur ^= 1;
     }
 }
 
-void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint64_t* keys,
-                              uint64_t* spare_keys, uint32_t* const vals[2])
+void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
+                              uint32_t* const vals[2])
 {
-    // every non-empty tile is claimed by exactly one of the three launches (by segment length); the others exit at
-    // once.  A single-entry tile is claimed too: its 64-bit key is only written here.
-    hipLaunchKernelGGL((segment_sort_small_kernel<8, ST>), dim3(T), dim3(ST), 0, s, ranges, 0, depth, keys, vals[0]);
-    hipLaunchKernelGGL((segment_sort_small_kernel<8, 2 * ST>), dim3(T), dim3(2 * ST), 0, s, ranges, ST * 8, depth, keys,
+    // every tile with two or more entries is claimed by exactly one of the three launches (by segment length); the
+    // others exit at once
+    hipLaunchKernelGGL((segment_sort_small_kernel<8, ST>), dim3(T), dim3(ST), 0, s, ranges, 0, depth, vals[0]);
+    hipLaunchKernelGGL((segment_sort_small_kernel<8, 2 * ST>), dim3(T), dim3(2 * ST), 0, s, ranges, ST * 8, depth,
                        vals[0]);
-    hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T), dim3(ST), 0, s, ranges, depth, keys, vals[0], spare_keys,
+    hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T), dim3(ST), 0, s, ranges, depth, keys[0], vals[0], keys[1],
                        vals[1]);
 }

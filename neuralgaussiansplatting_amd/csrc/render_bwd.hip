@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             const float G = exp_nonpos(power);
             const float alpha = fminf(0.99f, q.w * G);
             const bool live = have && pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(live) == 0ull) continue;  // wave-uniform
+            if (wave_mask(live) == 0ull) continue;  // wave-uniform
 
             // Every lane evaluates the body.  A dead lane (pixel that does not blend this splat) runs it with
             // alpha = 0, which leaves its state untouched without a single select: T / (1 - 0) = T, the
@@ -199,18 +199,18 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             const v2f col_rg = {col.x, col.y};
             // `rec` is the colour accumulated behind this splat (the reference's accum_rec after its update,
             // backward.cu:503-513)
-            const v2f d_rg = (col_rg - rec_rg) * dp_rg;
-            float dL_dalpha = d_rg.x + d_rg.y;
-            dL_dalpha += (col.z - rec_b) * dpb;
-            dL_dalpha *= Tn;
-            dL_dalpha += (-T_final * inv) * bgdot;
+            // From here on only gradients are formed (compared within a tolerance, and summed by atomics in no
+            // fixed order anyway): products and sums are fused where that saves an instruction.
+            const v2f d_rg = col_rg - rec_rg;
+            float dL_dalpha = fmaf(col.z - rec_b, dpb, fmaf(d_rg.y, dp_rg.y, d_rg.x * dp_rg.x));
+            dL_dalpha = fmaf(dL_dalpha, Tn, (-T_final * inv) * bgdot);
             dL_dalpha = live ? dL_dalpha : 0.0f;
             const float Gl = live ? G : 0.0f;
             const float dL_dG = q.w * dL_dalpha;
             const v2f gd = Gl * d;  // {G dx, G dy}
             const v2f gx = {gd.x, gd.x}, gy = {gd.y, gd.y};
             // {dG/ddelx, dG/ddely} = -gdx * {a, b} - gdy * {b, c}
-            const v2f dG = -gx * (v2f){q.x, q.y} - gy * (v2f){q.y, q.z};
+            const v2f dG = -__builtin_elementwise_fma(gy, (v2f){q.y, q.z}, gx * (v2f){q.x, q.y});
             const v2f v01 = (dL_dG * dG) * ddel;            // ACC_DX, ACC_DY
             const v2f h = -0.5f * gd;
             const v2f v23 = ((v2f){h.x, h.x} * d) * dL_dG;  // ACC_CON_A, ACC_CON_B
@@ -222,8 +222,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             // the next one = this splat blended over what was behind it (same expression the reference
             // evaluates one step later from its last_alpha / last_color)
             T = Tn;
-            rec_rg = alpha_l * col_rg + om * rec_rg;
-            rec_b = alpha_l * col.z + om * rec_b;
+            rec_rg = __builtin_elementwise_fma((v2f){alpha_l, alpha_l}, col_rg, om * rec_rg);
+            rec_b = fmaf(alpha_l, col.z, om * rec_b);
 
             // Sum over the quadrant's 16 pixels: four exchange steps, each halving the number of registers.
             const float a01 = row_fold<DPP_ROW_MIRROR>(v01.x, v01.y, up8);

@@ -106,5 +106,9 @@ __device__ __forceinline__ float exp_nonpos(float x)
     return ldexpf(__builtin_amdgcn_exp2f((ph - n) + pl), (int)n);
 }
 
+// Wave mask of a lane predicate, straight from the comparison that produced it (the generic __ballot first turns
+// the predicate into an integer register and compares that again).
+__device__ __forceinline__ unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // Index of the lowest set bit of a non-zero wave mask.
 __device__ __forceinline__ int lowest_lane(unsigned long long m) { return __builtin_ctzll(m); }

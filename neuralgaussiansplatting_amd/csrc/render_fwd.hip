@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
         nc = r[2].x;
     }
     for (int base = 0; base < n; base += 64) {
-        if (__ballot(!done) == 0ull) break;  // every pixel of the block is saturated (or outside the image)
+        if (wave_mask(!done) == 0ull) break;  // every pixel of the block is saturated (or outside the image)
         const float4 a = na, b = nb;
         const float c = nc;
         const bool have = base + lane < n;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
                 rec[lane][2] = make_float4(b.z, b.w, c, 0.0f);
             }
         }
-        unsigned long long mask = __ballot(reach);
+        unsigned long long mask = wave_mask(reach);
         while (mask) {
             const int j = lowest_lane(mask);
             mask &= mask - 1ull;
@@ -86,12 +86,14 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
             const bool stop = hit && test_T < 0.0001f;
             const bool blend = hit && !stop;
             done = done || stop;
-            Cr = blend ? Cr + col.x * alpha * T : Cr;
-            Cg = blend ? Cg + col.y * alpha * T : Cg;
-            Cb = blend ? Cb + col.z * alpha * T : Cb;
+            // (colour * alpha) * T added with one rounding, as the reference's build contracts the same expression
+            // (forward.cu:355-356 compiled with nvcc's default -fmad=true)
+            Cr = blend ? fmaf(col.x * alpha, T, Cr) : Cr;
+            Cg = blend ? fmaf(col.y * alpha, T, Cg) : Cg;
+            Cb = blend ? fmaf(col.z * alpha, T, Cb) : Cb;
             T = blend ? test_T : T;
             last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
-            if (__ballot(!done) == 0ull) break;
+            if (wave_mask(!done) == 0ull) break;
         }
     }
     if (inside) {

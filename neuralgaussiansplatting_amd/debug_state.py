@@ -27,10 +27,19 @@ def decode_state(_C, P, R, W, H, geom, binning, img):
         tile_rect=_view(geom, gl["tile_rect"], np.uint32, 2 * P).reshape(P, 2),
         tiles_touched=_view(geom, gl["tiles_touched"], np.uint32, P),
         clamped_bits=_view(geom, gl["clamped_bits"], np.uint8, P),
-        keys_sorted=_view(binning, bl["sorted_keys"], np.uint64, R),
         point_list=_view(binning, bl["point_list"], np.uint32, R),
         ranges=_view(img, il["ranges"], np.uint32, 2 * T).reshape(T, 2),
     )
+    # The sorted 64-bit keys of the reference's BinningState (tile << 32 | depth bits, rasterizer_impl.cu:88-109) are
+    # not stored by the library; what they would hold follows from the list, the ranges and the depth array.  An
+    # entry no range covers (there is none when the binning is right) keeps the all-ones key, which never matches.
+    tile_of = np.full(R, 0xFFFFFFFF, np.uint64)
+    rg = out["ranges"].astype(np.int64)
+    for t in np.nonzero(rg[:, 1] > rg[:, 0])[0]:
+        tile_of[rg[t, 0]:rg[t, 1]] = t
+    depth_bits = out["depths"].view(np.uint32)[out["point_list"].astype(np.int64)].astype(np.uint64) if R else \
+        np.zeros(0, np.uint64)
+    out["keys_sorted"] = (tile_of << np.uint64(32)) | depth_bits
     # per tile in thread order: 2x2 blocks of 8x8 pixels (one per wave), each 2x2 quadrants of 4x4 pixels (one per
     # 16-lane row of the wave), row-major inside a quadrant
     ft = _view(img, il["final_T"], np.float32, T * 256).reshape(gy, gx, 2, 2, 2, 2, 4, 4)

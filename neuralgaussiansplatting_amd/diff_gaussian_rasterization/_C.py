@@ -33,6 +33,7 @@ def lib():
             getattr(L, name).restype = ctypes.c_size_t
         L.ngs_required_binning_bytes.argtypes = [ctypes.c_longlong]
         L.ngs_rasterize_forward.restype = ctypes.c_int
+        L.ngs_rasterize_forward_presized.restype = ctypes.c_int
         L.ngs_rasterize_backward.restype = ctypes.c_int
         L.ngs_rasterize_backward_sh_adam.restype = ctypes.c_int
         L.ngs_mark_visible.restype = ctypes.c_int
@@ -96,9 +97,14 @@ class _Growable:
         return self.ptr
 
 
-# Size the binning buffer had to have in the previous call with the same problem shape, per (device, P, W, H):
-# consecutive calls of a training or rendering loop need nearly the same amount.
-_binning_hint = {}
+# Instance count of the previous call per (device, W, H): consecutive calls of a training or rendering loop produce
+# nearly the same number of instances (also across densification steps, which change the number of Gaussians by a few
+# percent), so the next call sizes its binning buffer from it up front and queues every stage without waiting for
+# its own count.  A call whose count exceeds the estimate repeats the stages after the count inside the library.
+_instance_hint = {}
+# Tests and experiments: an int here replaces the estimate (0 = wait for the count before sizing the buffer, as the
+# reference does); None = use the estimate.
+forced_binning_capacity = None
 
 
 def _stream(device):
@@ -117,24 +123,30 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     means3D, colors, opacity, scales, rotations, cov3D_precomp, sh = (
         _f32(x, dev) for x in (means3D, colors, opacity, scales, rotations, cov3D_precomp, sh))
     background, viewmatrix, projmatrix, campos = (_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
-    hint_key = (dev.index, P, W, H)
-    hint = _binning_hint.get(hint_key, 0)
-    geom, binning, img = _Growable(dev), _Growable(dev, hint + hint // 16), _Growable(dev)
+    hint_key = (dev.index, W, H)
+    hint_P, hint_R = _instance_hint.get(hint_key, (0, 0))
+    capacity = 0
+    if hint_R and 2 * hint_P >= P and hint_P <= 2 * P:  # a scene of about the same size: the count follows P
+        est = hint_R * P // hint_P
+        capacity = min(est + est // 8 + 4096, 0x7fffffff)
+    if forced_binning_capacity is not None:
+        capacity = int(forced_binning_capacity)
+    geom, binning, img = _Growable(dev), _Growable(dev), _Growable(dev)
     rendered = ctypes.c_int(0)
     if P != 0:
         out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         M = sh.size(1) if sh.numel() != 0 else 0
         with torch.cuda.device(dev):
-            _check(lib().ngs_rasterize_forward(
+            _check(lib().ngs_rasterize_forward_presized(
                 geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), _ptr(background), W, H,
                 _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), ctypes.c_float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy), int(bool(prefiltered)), _ptr(out_color),
-                _ptr(radii), int(bool(debug)), _stream(dev), ctypes.byref(rendered)))
-        if len(_binning_hint) > 256:  # shapes keep changing (densification): forget the old ones
-            _binning_hint.clear()
-        _binning_hint[hint_key] = binning.asked
+                _ptr(radii), int(bool(debug)), _stream(dev), ctypes.byref(rendered), ctypes.c_longlong(capacity)))
+        if len(_instance_hint) > 256:
+            _instance_hint.clear()
+        _instance_hint[hint_key] = (P, rendered.value)
     else:
         out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
         radii = torch.zeros((P,), dtype=torch.int32, device=dev)
@@ -418,10 +430,10 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 def state_layout(P, R, W, H):
     """Byte offsets of the intermediates inside the three state buffers (parity tests)."""
     g = (ctypes.c_size_t * 10)()
-    b = (ctypes.c_size_t * 2)()
+    b = (ctypes.c_size_t * 1)()
     i = (ctypes.c_size_t * 3)()
     lib().ngs_state_layout(int(P), ctypes.c_longlong(int(R)), int(W), int(H), g, b, i)
     names_g = ("splat_record", "depth", "tile_rect", "tiles_touched", "internal_radii",
                "clamped_bits", "block_sums", "block_offsets", "misc", "grad_accumulator")
-    return (dict(zip(names_g, g)), dict(zip(("sorted_keys", "point_list"), b)),
+    return (dict(zip(names_g, g)), dict(zip(("point_list",), b)),
             dict(zip(("final_T", "n_contrib", "ranges"), i)))

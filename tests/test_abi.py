@@ -38,11 +38,11 @@ def test_size_queries_and_layout_need_no_gpu():
     assert 0 < g1 < g2
     assert lib.ngs_required_geometry_bytes(0) >= 0
     assert lib.ngs_required_image_bytes(1920, 1080) > 120 * 68 * 256 * 8
-    assert lib.ngs_required_binning_bytes(1_000_000) >= 1_000_000 * 24
+    assert lib.ngs_required_binning_bytes(1_000_000) >= 1_000_000 * 16
     gl, bl, il = _C.state_layout(1000, 5000, 64, 48)
     offs = list(gl.values())
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert gl["grad_accumulator"] + 1000 * 64 <= g1
-    assert bl["sorted_keys"] % 256 == 0 and il["ranges"] % 256 == 0
+    assert bl["point_list"] == 0 and il["ranges"] % 256 == 0
     assert lib.ngs_last_error() == b""
     assert lib.ngs_profile_stage_count() == 17

@@ -32,7 +32,7 @@ def dgr():
 
 
 def run_hip(dgr, c, dL_dpix=None, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0, prefiltered=False,
-            debug=False):
+            debug=False, binning_capacity=None):
     dev = torch.device("cuda:0")
     sc, cam = c["scene"], c["cam"]
     e = torch.empty(0)
@@ -42,9 +42,13 @@ def run_hip(dgr, c, dL_dpix=None, colors_precomp=None, cov3D_precomp=None, scale
             scale_modifier, e if cov3D_precomp is None else g(cov3D_precomp), g(cam.world_view_transform),
             g(cam.full_proj_transform), c["tanfovx"], c["tanfovy"], c["H"], c["W"],
             g(sc.shs) if colors_precomp is None else e, c["D"], g(cam.camera_center), prefiltered, debug)
-    R, color, radii, geom, binning, img = dgr._C.rasterize_gaussians(*args)
+    dgr._C.forced_binning_capacity = binning_capacity
+    try:
+        R, color, radii, geom, binning, img = dgr._C.rasterize_gaussians(*args)
+    finally:
+        dgr._C.forced_binning_capacity = None
     torch.cuda.synchronize()
-    out = dict(R=R, color=color.cpu().numpy(), radii=radii.cpu().numpy())
+    out = dict(R=R, color=color.cpu().numpy(), radii=radii.cpu().numpy(), binning_bytes=binning.numel())
     P = sc.means3D.shape[0]
     if P:
         out.update(decode_state(dgr._C, P, R, c["W"], c["H"], geom, binning, img))
@@ -281,6 +285,35 @@ def test_crowded_tiles_take_the_long_segment_path(dgr, oracle):
     h = run_hip(dgr, c, dL_dpix=dL)
     check_forward(o, h)
     check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=32.0 * 32.0)
+
+
+@pytest.mark.parametrize("name", ["sh3_64x64", "big_splats", "crowded"])
+def test_presized_binning_buffer_any_capacity_same_result(name, dgr, oracle):
+    """The forward pass with the binning buffer sized from an estimate before the count is known: whatever the
+    estimate -- far too small (the library then repeats the stages with the right size), one short, exact,
+    generous -- count, lists, ranges, image and gradients are those of the call that waits for the count."""
+    c = case(P=24000, W=32, H=32, D=0, seed=37, log_scale=(-5.0, -4.0), extent=(0.5, 0.5, 1.3)) \
+        if name == "crowded" else case(**CASES[name])
+    dL = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(7))
+    o = oracle_forward(oracle, c)
+    ref = run_hip(dgr, c, dL_dpix=dL, binning_capacity=0)
+    check_forward(o, ref)
+    R = ref["R"]
+    assert R == o["num_rendered"] > 100
+    for cap in (1, R // 3, R - 1, R, R + 1, 3 * R + 5000):
+        h = run_hip(dgr, c, dL_dpix=dL, binning_capacity=cap)
+        assert h["R"] == R
+        for k in ("point_list", "ranges", "keys_sorted", "color", "final_T", "n_contrib", "radii"):
+            np.testing.assert_array_equal(h[k], ref[k], err_msg="%s at capacity %d" % (k, cap))
+        for k, v in ref["grads"].items():
+            big = float(np.abs(v).max())
+            assert float(np.abs(h["grads"][k] - v).max()) <= 1e-5 * big + 1e-12, (k, cap)
+        # the buffer the caller ends up with holds max(capacity, count) instances
+        assert h["binning_bytes"] >= 16 * max(cap, R)
+    # the estimate the binding keeps from the previous call: same results again, no explicit capacity
+    h = run_hip(dgr, c, dL_dpix=dL)
+    np.testing.assert_array_equal(h["point_list"], ref["point_list"])
+    np.testing.assert_array_equal(h["color"], ref["color"])
 
 
 def test_debug_mode_same_result(dgr, oracle):
