@@ -32,7 +32,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from neuralgaussiansplatting_amd import synthetic, view_parallel  # noqa: E402
+from neuralgaussiansplatting_amd import build_id, synthetic, view_parallel  # noqa: E402
 from neuralgaussiansplatting_amd.debug_state import decode_state  # noqa: E402
 from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C  # noqa: E402
 
@@ -88,7 +88,8 @@ def cpu_baseline(scene, cam, W, H, D, tanx, tany, dL):
                  rotations=a(scene.rotations))
     t2 = time.time()
     return {"value": W * H / (t2 - t0) / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": "1 forward+backward of the same view and scene (fwd %.2f s, bwd %.2f s, R=%d)"
+            "sample": "1 forward+backward of the same view and scene (fwd %.2f s, bwd %.2f s, R=%d); gcc -O3, "
+                      "OpenMP over Gaussians / tiles, backward sums in per-thread copies (no atomics)"
                       % (t1 - t0, t2 - t1, st["num_rendered"])}
 
 
@@ -108,6 +109,12 @@ def main():
                          "second loop for the train iters/s figure; default: min(--steps, 20), 0 to skip")
     ap.add_argument("--no-idxmap", action="store_true",
                     help="skip the side measurements: the index-map operator of the reference's second rasterizer (forward+backward) and the nearest-neighbour scene initialisation")
+    ap.add_argument("--log-scale-offset", type=float, default=0.0,
+                    help="added to the configuration's log-scale range: larger splats, more instances per Gaussian "
+                         "(the configurations give about 4; +0.6 about 8, +1.1 about 16 at c4); reported in config")
+    ap.add_argument("--stage-steps", type=int, default=None,
+                    help="steps of the separate loop that times the stages with HIP events (default min(--steps, 30)); "
+                         "the headline loop runs without them")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
@@ -131,8 +138,9 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    P, W, H, D, M, _, _ = synthetic.CONFIGS[args.config]
-    scene_cpu, W, H = synthetic.make_config(args.config, seed=1234)  # same seed everywhere: replicated parameters
+    P, W, H, D, M, ls, ext = synthetic.CONFIGS[args.config]
+    ls = (ls[0] + args.log_scale_offset, ls[1] + args.log_scale_offset)
+    scene_cpu = synthetic.make_scene(P, D, ls, ext, 1234, M)  # same seed everywhere: replicated parameters
     scene = scene_cpu.to(dev)
     cam = synthetic.make_view(W, H, index=rank, count=8, device=dev)  # one orbit view per rank
     tanx, tany = synthetic.tan_half_fov(cam)
@@ -181,8 +189,8 @@ def main():
     # workload statistics of this rank's view (cost is linear in them)
     R = aux["num_rendered"]
     vis = float((radii > 0).float().mean())
-    _C.profile_enable(not args.no_stage_timing)
-    _C.profile_read(reset=True)
+    # the headline loop runs without per-stage events; the stages are timed in a second, shorter loop
+    _C.profile_enable(False)
     with quiet_host():
         fence()
         t0 = time.perf_counter()
@@ -191,8 +199,18 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     note("timed steps done")
-    stages = _C.profile_read(reset=True)
-    _C.profile_enable(False)
+    stages = {}
+    if not args.no_stage_timing:
+        stage_steps = min(args.steps, 30) if args.stage_steps is None else args.stage_steps
+        _C.profile_enable(True)
+        _C.profile_read(reset=True)
+        with quiet_host():
+            for _ in range(stage_steps):
+                step()
+            torch.cuda.synchronize(dev)
+        stages = _C.profile_read(reset=True)
+        _C.profile_enable(False)
+        note("stage timing done")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -315,22 +333,34 @@ def main():
         roofline = None
         if dom is not None:
             ach = nbytes[dom] / (dom_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f).get(args.config, {}).get(dom)
+            # Counter-derived figures come from separate rocprofv3 --pmc passes (tools/collect_profiles.sh), not
+            # from this run: they are quoted only if the profiled build had the kernel sources this build has, and
+            # the line says which file and commit they come from.
+            here = build_id.kernel_sources_sha()
+
+            def profiled(fname):
+                path = os.path.join(ROOT, "profiles", fname)
+                if not os.path.exists(path) or args.log_scale_offset != 0.0:
+                    return None, None
+                with open(path) as f:
+                    doc = json.load(f)
+                src = doc.get("_source", {})
+                if src.get("kernel_sources_sha") != here:
+                    return None, "stale: profiles/%s was measured on kernel sources %s, this build is %s" % (
+                        fname, src.get("kernel_sources_sha", "unrecorded"), here)
+                return doc.get(args.config, {}).get(dom), "profiles/%s (%s) at commit %s, kernel sources %s" % (
+                    fname, src.get("raw", "rocprofv3 --pmc passes"), src.get("commit", "unrecorded"), here)
+
+            traffic, traffic_source = profiled("hbm_traffic.json")
             # the compositing kernels are limited by vector-ALU issue, not by HBM: quote the counter-derived issue
-            # fraction (share of the one-wave64-FP32-instruction-per-2-cycles peak) of the last profiled build too
-            valu = None
-            vpath = os.path.join(ROOT, "profiles", "valu_issue.json")
-            if os.path.exists(vpath):
-                with open(vpath) as f:
-                    valu = json.load(f).get(args.config, {}).get(dom)
+            # fraction (share of the one-wave64-FP32-instruction-per-2-cycles peak) as well
+            valu, valu_source = profiled("valu_issue.json")
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes": int(nbytes[dom]),
-                        "valu_issue_frac": valu}
+                        "traffic_source": traffic_source, "avg_launch_ms": round(dom_ms, 4),
+                        "algorithmic_bytes": int(nbytes[dom]), "valu_issue_frac": valu, "valu_source": valu_source,
+                        "limiter": "vector-ALU issue (valu_issue_frac), not HBM: the kernel moves less than its "
+                                   "algorithmic bytes" if dom.startswith("render_") else "HBM"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene_cpu, synthetic.make_view(W, H, index=0, count=8), W, H, D, tanx, tany, dL)
@@ -360,11 +390,16 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "iters_per_s": round(world * args.steps / elapsed, 2),
-            "config": {"workload": "%s: %d Gaussians, %dx%d, SH degree %d (M=%d), one orbit view per GPU, "
-                                   "fwd+bwd%s" % (args.config, P, W, H, D, M,
+            "config": {"workload": "%s%s: %d Gaussians, %dx%d, SH degree %d (M=%d), one orbit view per GPU, "
+                                   "fwd+bwd%s" % (args.config,
+                                                  "" if args.log_scale_offset == 0.0 else
+                                                  " with log-scale offset %+.2f" % args.log_scale_offset,
+                                                  P, W, H, D, M,
                                                   " + %s gradient exchange of %d floats per rank"
                                                   % (args.exchange, exchanged_floats) if world > 1 else ""),
                        "gaussians": P, "width": W, "height": H, "sh_degree": D, "instances_R": int(R),
+                       "instances_per_gaussian": round(R / P, 2), "log_scale": [round(v, 3) for v in ls],
+                       "kernel_sources_sha": build_id.kernel_sources_sha(),
                        "visible_fraction": round(vis, 4), "instances_per_tile_mean": round(float(per_tile.mean()), 1),
                        "instances_per_tile_max": int(per_tile.max()),
                        "last_contributor_per_pixel_mean": round(float(stt["n_contrib"].mean()), 1),

@@ -441,79 +441,121 @@ void ngs_oracle_render_forward(int W, int H, const uint32_t* ranges, const uint3
     }
 }
 
-static void accum(float* dst, float v)
+/*
+ * One tile of dgr/cuda_rasterizer/backward.cu:399-557: every pixel of the tile walks the tile's list back to front
+ * and adds its terms to d_xy [P][3] (x,y used), d_conic [P][4] (slots 0,1,3), d_opac [P], d_col [P][3] with plain
+ * additions, pixel after pixel (the reference's float-atomic order is unspecified).
+ */
+static void render_backward_tile(int tile, int W, int H, int gx, const uint32_t* ranges, const uint32_t* plist,
+                                 const float* bg, const float* xy, const float* conic_o, const float* feat,
+                                 const float* final_T, const uint32_t* n_contrib, const float* dpix, float* d_xy,
+                                 float* d_conic, float* d_opac, float* d_col)
 {
-#pragma omp atomic
-    *dst += v;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    int tx = tile % gx, ty = tile / gx;
+    uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
+    for (int ly = 0; ly < TILE_H; ly++)
+        for (int lx = 0; lx < TILE_W; lx++) {
+            int px = tx * TILE_W + lx, py = ty * TILE_H + ly;
+            if (px >= W || py >= H) continue;
+            size_t pid = (size_t)W * py + px;
+            const float T_final = final_T[pid];
+            float T = T_final;
+            uint32_t contributor = hi - lo;
+            const uint32_t last = n_contrib[pid];
+            float rec[3] = {0, 0, 0}, last_c[3] = {0, 0, 0}, last_a = 0, dp[3];
+            for (int ch = 0; ch < 3; ch++) dp[ch] = dpix[(size_t)ch * H * W + pid];
+            for (uint32_t k = hi; k-- > lo;) {
+                contributor--;
+                if (contributor >= last) continue;
+                uint32_t g = plist[k];
+                float dx = xy[2 * g] - (float)px, dy = xy[2 * g + 1] - (float)py;
+                const float* co = conic_o + 4 * g;
+                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0.0f) continue;
+                float G = expf(power);
+                float alpha = fminf(0.99f, co[3] * G);
+                if (alpha < 1.0f / 255.0f) continue;
+                T = T / (1.f - alpha);
+                float w = alpha * T;
+                float dL_da = 0.0f;
+                for (int ch = 0; ch < 3; ch++) {
+                    float c = feat[3 * g + ch];
+                    rec[ch] = last_a * last_c[ch] + (1.f - last_a) * rec[ch];
+                    last_c[ch] = c;
+                    dL_da += (c - rec[ch]) * dp[ch];
+                    d_col[3 * g + ch] += w * dp[ch];
+                }
+                dL_da *= T;
+                last_a = alpha;
+                float bgdot = 0;
+                for (int ch = 0; ch < 3; ch++) bgdot += bg[ch] * dp[ch];
+                dL_da += (-T_final / (1.f - alpha)) * bgdot;
+                float dL_dG = co[3] * dL_da;
+                float gdx = G * dx, gdy = G * dy;
+                float dG_dx = -gdx * co[0] - gdy * co[1];
+                float dG_dy = -gdy * co[2] - gdx * co[1];
+                d_xy[3 * g] += dL_dG * dG_dx * ddelx_dx;
+                d_xy[3 * g + 1] += dL_dG * dG_dy * ddely_dy;
+                d_conic[4 * g] += -0.5f * gdx * dx * dL_dG;
+                d_conic[4 * g + 1] += -0.5f * gdx * dy * dL_dG;
+                d_conic[4 * g + 3] += -0.5f * gdy * dy * dL_dG;
+                d_opac[g] += G * dL_da;
+            }
+        }
 }
 
 /*
- * dgr/cuda_rasterizer/backward.cu:399-557.  Accumulates (callers zero the
- * outputs): d_xy [P][3] (x,y used), d_conic [P][4] (slots 0,1,3), d_opac [P],
- * d_col [P][3].  Single-threaded runs add in a fixed order (tile, pixel,
- * back-to-front); the reference's float-atomic order is unspecified.
+ * dgr/cuda_rasterizer/backward.cu:399-557 over all tiles.  Accumulates into the outputs (callers zero them).
+ * With one thread the additions happen in a fixed order (tile, pixel, back to front) -- the mode the parity tests
+ * use.  With several threads every thread adds into private copies of the four arrays (11 floats per Gaussian
+ * each), which are summed afterwards: no atomics inside the pixel loop, at the price of an addition order that
+ * follows the schedule.  Returns 0, or 1 if the private copies could not be allocated.
  */
-void ngs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* plist, const float* bg,
-                                const float* xy, const float* conic_o, const float* feat, const float* final_T,
-                                const uint32_t* n_contrib, const float* dpix, float* d_xy, float* d_conic,
-                                float* d_opac, float* d_col)
+int ngs_oracle_render_backward(int P, int W, int H, const uint32_t* ranges, const uint32_t* plist, const float* bg,
+                               const float* xy, const float* conic_o, const float* feat, const float* final_T,
+                               const uint32_t* n_contrib, const float* dpix, float* d_xy, float* d_conic,
+                               float* d_opac, float* d_col)
 {
     const int gx = (W + TILE_W - 1) / TILE_W, gy = (H + TILE_H - 1) / TILE_H;
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int tile = 0; tile < gx * gy; tile++) {
-        int tx = tile % gx, ty = tile / gx;
-        uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
-        for (int ly = 0; ly < TILE_H; ly++)
-            for (int lx = 0; lx < TILE_W; lx++) {
-                int px = tx * TILE_W + lx, py = ty * TILE_H + ly;
-                if (px >= W || py >= H) continue;
-                size_t pid = (size_t)W * py + px;
-                const float T_final = final_T[pid];
-                float T = T_final;
-                uint32_t contributor = hi - lo;
-                const uint32_t last = n_contrib[pid];
-                float rec[3] = {0, 0, 0}, last_c[3] = {0, 0, 0}, last_a = 0, dp[3];
-                for (int ch = 0; ch < 3; ch++) dp[ch] = dpix[(size_t)ch * H * W + pid];
-                for (uint32_t k = hi; k-- > lo;) {
-                    contributor--;
-                    if (contributor >= last) continue;
-                    uint32_t g = plist[k];
-                    float dx = xy[2 * g] - (float)px, dy = xy[2 * g + 1] - (float)py;
-                    const float* co = conic_o + 4 * g;
-                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > 0.0f) continue;
-                    float G = expf(power);
-                    float alpha = fminf(0.99f, co[3] * G);
-                    if (alpha < 1.0f / 255.0f) continue;
-                    T = T / (1.f - alpha);
-                    float w = alpha * T;
-                    float dL_da = 0.0f;
-                    for (int ch = 0; ch < 3; ch++) {
-                        float c = feat[3 * g + ch];
-                        rec[ch] = last_a * last_c[ch] + (1.f - last_a) * rec[ch];
-                        last_c[ch] = c;
-                        dL_da += (c - rec[ch]) * dp[ch];
-                        accum(d_col + 3 * g + ch, w * dp[ch]);
-                    }
-                    dL_da *= T;
-                    last_a = alpha;
-                    float bgdot = 0;
-                    for (int ch = 0; ch < 3; ch++) bgdot += bg[ch] * dp[ch];
-                    dL_da += (-T_final / (1.f - alpha)) * bgdot;
-                    float dL_dG = co[3] * dL_da;
-                    float gdx = G * dx, gdy = G * dy;
-                    float dG_dx = -gdx * co[0] - gdy * co[1];
-                    float dG_dy = -gdy * co[2] - gdx * co[1];
-                    accum(d_xy + 3 * g, dL_dG * dG_dx * ddelx_dx);
-                    accum(d_xy + 3 * g + 1, dL_dG * dG_dy * ddely_dy);
-                    accum(d_conic + 4 * g, -0.5f * gdx * dx * dL_dG);
-                    accum(d_conic + 4 * g + 1, -0.5f * gdx * dy * dL_dG);
-                    accum(d_conic + 4 * g + 3, -0.5f * gdy * dy * dL_dG);
-                    accum(d_opac + g, G * dL_da);
-                }
-            }
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+#endif
+    if (threads <= 1) {
+        for (int tile = 0; tile < gx * gy; tile++)
+            render_backward_tile(tile, W, H, gx, ranges, plist, bg, xy, conic_o, feat, final_T, n_contrib, dpix,
+                                 d_xy, d_conic, d_opac, d_col);
+        return 0;
     }
+    const size_t per = (size_t)11 * (size_t)P; /* 3 + 4 + 1 + 3 floats per Gaussian */
+    float* priv = (float*)calloc((size_t)threads * per, sizeof(float));
+    if (!priv) return 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int me = 0;
+#ifdef _OPENMP
+        me = omp_get_thread_num();
+#endif
+        float* base = priv + (size_t)me * per;
+        float *p_xy = base, *p_conic = base + (size_t)3 * P, *p_opac = base + (size_t)7 * P,
+              *p_col = base + (size_t)8 * P;
+#pragma omp for schedule(dynamic, 1)
+        for (int tile = 0; tile < gx * gy; tile++)
+            render_backward_tile(tile, W, H, gx, ranges, plist, bg, xy, conic_o, feat, final_T, n_contrib, dpix,
+                                 p_xy, p_conic, p_opac, p_col);
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++)
+        for (int t = 0; t < threads; t++) {
+            const float* base = priv + (size_t)t * per;
+            for (int k = 0; k < 3; k++) d_xy[3 * i + k] += base[3 * (size_t)i + k];
+            for (int k = 0; k < 4; k++) d_conic[4 * i + k] += base[(size_t)3 * P + 4 * (size_t)i + k];
+            d_opac[i] += base[(size_t)7 * P + i];
+            for (int k = 0; k < 3; k++) d_col[3 * i + k] += base[(size_t)8 * P + 3 * (size_t)i + k];
+        }
+    free(priv);
+    return 0;
 }
 
 /* dgr/cuda_rasterizer/backward.cu:144-274.  Writes d_means[i] and d_cov[6i..] for radii>0. */

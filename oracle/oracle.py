@@ -35,6 +35,7 @@ def lib():
         _lib.ngs_oracle_higher_msb.restype = ctypes.c_uint32
         _lib.ngs_oracle_threads.restype = ctypes.c_int
         _lib.ngs_oracle_preprocess.restype = ctypes.c_int
+        _lib.ngs_oracle_render_backward.restype = ctypes.c_int
         _lib.ngs_oracle_idxmap_forward.restype = ctypes.c_longlong
     return _lib
 
@@ -177,10 +178,11 @@ def backward(s, dL_dpix, means3D, viewmatrix, projmatrix, campos, bg, tanfovx, t
         for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors"):
             g[k][...] = np.asarray(stage1[k], np.float32).reshape(g[k].shape)
     else:
-        L.ngs_oracle_render_backward(W, H, _p(s["ranges"]), _p(s["point_list"]), _p(bg), _p(s["means2D"]),
-                                     _p(s["conic_opacity"]), _p(s["features"]), _p(s["final_T"]), _p(s["n_contrib"]),
-                                     _p(dL_dpix), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]),
-                                     _p(g["dL_dcolors"]))
+        if L.ngs_oracle_render_backward(P, W, H, _p(s["ranges"]), _p(s["point_list"]), _p(bg), _p(s["means2D"]),
+                                        _p(s["conic_opacity"]), _p(s["features"]), _p(s["final_T"]),
+                                        _p(s["n_contrib"]), _p(dL_dpix), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]),
+                                        _p(g["dL_dopacity"]), _p(g["dL_dcolors"])) != 0:
+            raise MemoryError("oracle: per-thread gradient accumulators could not be allocated")
     fy = np.float32(H) / (np.float32(2.0) * np.float32(tanfovy))
     fx = np.float32(W) / (np.float32(2.0) * np.float32(tanfovx))
     cov3d = cov3D_precomp if cov3D_precomp is not None and cov3D_precomp.size else s["cov3D"]

@@ -11,5 +11,5 @@ cp $SRC/trace/*/*_kernel_stats.csv profiles/${TAG}_c4_final_kernel_stats.csv
 python3 tools/kernel_stats_md.py profiles/${TAG}_c4_final_kernel_stats.csv "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline" > profiles/${TAG}_c4_final_kernel_stats.md
 python3 tools/pmc_summary.py --fetch $SRC/pmc_fetch --write $SRC/pmc_write --config c4 --fwd-runs 5 --bwd-runs 4 \
     --out profiles/hbm_traffic.json --raw profiles/${TAG}_c4_pmc_traffic.json
-python3 tools/pmc_valu_summary.py $SRC/pmc_valu profiles/valu_issue.json c4 > profiles/${TAG}_c4_valu.md
+python3 tools/pmc_valu_summary.py $SRC/pmc_valu profiles/valu_issue.json c4 profiles/${TAG}_c4_valu.md > profiles/${TAG}_c4_valu.md
 python3 tools/results_tables.py $TAG

@@ -85,10 +85,8 @@ def main():
     with open(a.raw, "w") as f:
         json.dump({"unit": "KiB per launch as printed by rocprofv3", "kernels": raw, "stages_per_step": stages,
                    "forward_runs": a.fwd_runs, "backward_runs": a.bwd_runs}, f, indent=1)
-    table = {}
-    if os.path.exists(a.out):
-        with open(a.out) as f:
-            table = json.load(f)
+    from _source import merged_table, source_record
+    table = merged_table(a.out, source_record(a.raw))
     table[a.config] = {s: int(v["hbm_bytes"]) for s, v in stages.items()}
     with open(a.out, "w") as f:
         json.dump(table, f, indent=1)

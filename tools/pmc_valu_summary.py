@@ -52,10 +52,8 @@ def main():
             100 * c.get("SQ_WAIT_ANY", 0) / n / wave_q if wave_q else 0,
             100 * c.get("SQ_WAIT_INST_ANY", 0) / n / wave_q if wave_q else 0))
     if len(sys.argv) > 3:
-        table = {}
-        if os.path.exists(sys.argv[2]):
-            with open(sys.argv[2]) as f:
-                table = json.load(f)
+        from _source import merged_table, source_record
+        table = merged_table(sys.argv[2], source_record(sys.argv[4] if len(sys.argv) > 4 else "rocprofv3 --pmc SQ_* pass"))
         table[sys.argv[3]] = fractions
         with open(sys.argv[2], "w") as f:
             json.dump(table, f, indent=1)

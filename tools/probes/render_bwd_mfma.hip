@@ -1,0 +1,273 @@
+// EXPERIMENT, not part of the library (kept for the record; drop it into csrc/render_bwd.hip to rebuild it).
+// The backward compositing kernel with its 16-pixel reduction moved from DPP row exchanges (25 vector instructions
+// per step) to nine v_mfma_f32_16x16x4_f32 into one shared accumulator.  Results agree with the shipped kernel to
+// 3e-7, but the launch takes 1.32 ms instead of 0.86 ms at 3 M Gaussians / 1080p on MI355X: the FP32 matrix
+// instruction runs at the FP32 vector rate (64 FLOP per clock and SIMD), so nine of them cost what 144 vector
+// instructions cost, and they did not overlap with the vector work of the other waves.
+// Per-tile back-to-front compositing gradient.  Same tiling and LDS staging
+// as the forward kernel, traversed in reverse; per-pixel arithmetic follows
+// cuda_rasterizer/backward.cu:399-557 of the reference.  What differs:
+//
+//  * The traversal starts at the tile's deepest contributor (the maximum of
+//    the per-pixel last-contributor indices the forward pass stored) instead
+//    of at the end of the tile's list: entries behind it are skipped by every
+//    pixel in the reference too (backward.cu:486-488), so they are never staged.
+//  * Every 16-lane row of a wave owns one 4x4 pixel quadrant and walks its OWN
+//    list of splats: per batch of staged splats each wave ballots, quadrant by
+//    quadrant, which splats can reach the quadrant and lie in front of its
+//    deepest contributor, compacts the survivors into four short index lists,
+//    and then all four rows step through their lists side by side.  A small
+//    quadrant is touched by far fewer splats than a tile, and a touching splat
+//    covers most of its pixels, so few lanes run the arithmetic for nothing.
+//  * Reduction: the reference issues nine global float atomics per (pixel,
+//    splat) pair.  Here the nine partials are summed over the 16 pixels of the
+//    quadrant by the MATRIX cores, which this kernel leaves idle otherwise: a
+//    quadrant's pixels sit in lanes 16 k + 4 Q + m (k, m = 0..3), so with the
+//    partial as the A operand (A[i][k] = lane 16 k + i) and a 0/1 selector as B
+//    (B[k][j] = [j == v]) one v_mfma_f32_16x16x4_f32 per partial v adds the four
+//    k of every i into column v of one shared 16x16 accumulator; its rows
+//    4 Q .. 4 Q + 3 land in the four result registers of lane 16 Q + v, three
+//    additions finish the sum, and lane 16 Q + v holds total v of quadrant Q --
+//    exact FP32 arithmetic throughout.  The totals are combined across
+//    quadrants and waves in an LDS table holding one row per staged splat, and
+//    each splat's row leaves the workgroup once per batch as ONE 64-byte-row
+//    group of global atomics into the [P][16] accumulator.
+#include "render_common.h"
+
+typedef float v2f __attribute__((ext_vector_type(2)));  // pairs of channels go through the packed-FP32 instructions
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define BWD_BATCH NGS_TILE_PIX  // splats staged per round
+
+// Pixel layout of the backward kernel inside a wave's 8x8 block: lane 16 k + 4 Q + m is pixel (x = m, y = k) of
+// quadrant Q (the forward kernel keeps a quadrant in 16 consecutive lanes; this kernel spreads it over the four
+// 16-lane groups because the matrix instruction sums over exactly that lane stride).  bwd_fwd_tid gives the thread
+// whose slot of final_T / n_contrib holds the pixel.
+__device__ __forceinline__ int bwd_fwd_tid(int tid)
+{
+    const int lane = tid & 63, k = lane >> 4, Q = (lane >> 2) & 3, m = lane & 3;
+    return (tid & ~63) | (Q << 4) | (k << 2) | m;
+}
+
+__global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
+    int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
+    const float4* __restrict__ splat_rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dpix, float* __restrict__ acc)
+{
+    // record k: [0] = {x, y, ln(255 opacity), -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
+    __shared__ float4 s_rec[BWD_BATCH][3];
+    __shared__ float s_acc[BWD_BATCH][ACC_USED];
+    __shared__ uint8_t s_list[NGS_TILE_PIX / 64][4][BWD_BATCH];  // per wave and quadrant: staged slots to visit
+    __shared__ uint32_t s_wmax[NGS_TILE_PIX / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int quad = (lane >> 2) & 3;  // the quadrant this lane's PIXEL belongs to
+    const int oquad = lane >> 4;       // the quadrant whose TOTALS this lane receives from the matrix unit
+    const int ocomp = lane & 15;       // ... and which of the nine totals (lanes with ocomp >= 9 receive nothing)
+    const int tile = blockIdx.x;
+    const int tx = tile % grid_x, ty = tile / grid_x;
+    const int ftid = bwd_fwd_tid(tid);
+    const int px = tx * NGS_TILE_W + tile_local_x(ftid), py = ty * NGS_TILE_H + tile_local_y(ftid);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    // corner pixel of this wave's 8x8 block; quadrant k spans [bx0 + 4 (k & 1), +3] x [by0 + 4 (k >> 1), +3]
+    const float bx0 = (float)(tx * NGS_TILE_W + (wave & 1) * NGS_WAVE_W);
+    const float by0 = (float)(ty * NGS_TILE_H + (wave >> 1) * NGS_WAVE_H);
+    const uint2 range = ranges[tile];
+
+    const size_t tp = (size_t)tile * NGS_TILE_PIX + ftid;
+    const float T_final = inside ? final_T[tp] : 0.0f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? n_contrib[tp] : 0u;
+    // deepest contributor of each quadrant, of this block (wave) and of the tile
+    uint32_t qmax = last_contributor;
+    qmax = max(qmax, (uint32_t)__shfl_xor((int)qmax, 1, 64));
+    qmax = max(qmax, (uint32_t)__shfl_xor((int)qmax, 2, 64));
+    qmax = max(qmax, (uint32_t)__shfl_xor((int)qmax, 16, 64));
+    qmax = max(qmax, (uint32_t)__shfl_xor((int)qmax, 32, 64));
+    const uint32_t qmax0 = (uint32_t)__builtin_amdgcn_readlane((int)qmax, 0);
+    const uint32_t qmax1 = (uint32_t)__builtin_amdgcn_readlane((int)qmax, 4);
+    const uint32_t qmax2 = (uint32_t)__builtin_amdgcn_readlane((int)qmax, 8);
+    const uint32_t qmax3 = (uint32_t)__builtin_amdgcn_readlane((int)qmax, 12);
+    const uint32_t wmax = max(max(qmax0, qmax1), max(qmax2, qmax3));
+    if (lane == 0) s_wmax[wave] = wmax;
+    __syncthreads();
+    const uint32_t tmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    if (tmax == 0) return;  // nothing in this tile was blended (block-uniform)
+
+    float dpr = 0.0f, dpg = 0.0f, dpb = 0.0f;
+    if (inside) {
+        const size_t pid = (size_t)W * py + px, plane = (size_t)W * H;
+        dpr = dL_dpix[pid];
+        dpg = dL_dpix[plane + pid];
+        dpb = dL_dpix[2 * plane + pid];
+    }
+    float bgdot = 0.0f;
+    bgdot += bg[0] * dpr;
+    bgdot += bg[1] * dpg;
+    bgdot += bg[2] * dpb;
+    v2f rec_rg = {0.0f, 0.0f};
+    float rec_b = 0.0f;
+    const v2f dp_rg = {dpr, dpg};
+    const v2f ddel = {(float)(0.5 * W), (float)(0.5 * H)};  // d(pixel offset)/d(ndc)
+    const v2f pix = {pxf, pyf};
+    // B operands of the nine matrix instructions: column selectors, B_v[k][j] = [j == v] (lane 16 k + j holds B[k][j])
+    float sel[ACC_USED];
+#pragma unroll
+    for (int v = 0; v < ACC_USED; v++) sel[v] = ocomp == v ? 1.0f : 0.0f;
+    uint8_t* const my_list = &s_list[wave][quad][0];
+    uint8_t* const out_list = &s_list[wave][oquad][0];
+
+    // Zero-based list positions tmax-1 ... 0 are walked in that order, BWD_BATCH per round;
+    // staged slot s of round r holds list position tmax-1 - r*BWD_BATCH - s.
+    const int rounds = (int)((tmax + BWD_BATCH - 1) / BWD_BATCH);
+    for (int r = 0; r < rounds; r++) {
+        __syncthreads();  // previous batch fully flushed before its LDS is reused
+        const int first = (int)tmax - 1 - r * BWD_BATCH;  // list position of slot 0
+        const int nb = min(BWD_BATCH, first + 1);
+        if (tid < nb) {
+            const uint32_t id = plist[range.x + (uint32_t)(first - tid)];
+            const float4* gr = splat_rec + 4 * (size_t)id;  // one 64-byte line per splat
+            const float4 a = gr[0];
+            const float4 b = gr[1];
+            const float c = gr[2].x;
+            s_rec[tid][0] = make_float4(a.x, a.y, splat_tau(b.y), 0.0f);
+            s_rec[tid][1] = make_float4(a.z, a.w, b.x, b.y);
+            s_rec[tid][2] = make_float4(b.z, b.w, c, __uint_as_float(id));
+        }
+#pragma unroll
+        for (int c = 0; c < ACC_USED; c++) s_acc[tid][c] = 0.0f;
+        __syncthreads();
+
+        // ---- which staged splats does each quadrant of this block have to visit? ----
+        int n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // wave-uniform list lengths
+        for (int chunk = 0; chunk < nb; chunk += 64) {
+            const int mine = chunk + lane;
+            bool r0 = false, r1 = false, r2 = false, r3 = false;
+            if (mine < nb) {
+                const uint32_t pos = (uint32_t)(first - mine);
+                const float4 p = s_rec[mine][0];
+                const float4 q = s_rec[mine][1];
+                const unsigned bits = splat_reaches_quadrants(p.x, p.y, q.x, q.y, q.z, p.z, bx0, by0);
+                r0 = pos < qmax0 && (bits & 1u);
+                r1 = pos < qmax1 && (bits & 2u);
+                r2 = pos < qmax2 && (bits & 4u);
+                r3 = pos < qmax3 && (bits & 8u);
+            }
+            const unsigned long long m0 = wave_mask(r0), m1 = wave_mask(r1), m2 = wave_mask(r2), m3 = wave_mask(r3);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (r0) s_list[wave][0][n0 + __popcll(m0 & below)] = (uint8_t)mine;
+            if (r1) s_list[wave][1][n1 + __popcll(m1 & below)] = (uint8_t)mine;
+            if (r2) s_list[wave][2][n2 + __popcll(m2 & below)] = (uint8_t)mine;
+            if (r3) s_list[wave][3][n3 + __popcll(m3 & below)] = (uint8_t)mine;
+            n0 += __popcll(m0);
+            n1 += __popcll(m1);
+            n2 += __popcll(m2);
+            n3 += __popcll(m3);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int my_n = quad == 0 ? n0 : quad == 1 ? n1 : quad == 2 ? n2 : n3;
+        const int out_n = oquad == 0 ? n0 : oquad == 1 ? n1 : oquad == 2 ? n2 : n3;
+        const int steps = max(max(n0, n1), max(n2, n3));
+
+        // ---- the four quadrants walk their lists side by side ----
+        // The records of the next step are requested before the arithmetic of the current one, so the LDS round
+        // trips (list entry, then record) overlap with it.
+        int j_next = 0 < my_n ? (int)my_list[0] : 0;
+        float4 p_next = s_rec[j_next][0], q_next = s_rec[j_next][1], col_next = s_rec[j_next][2];
+        int j_after = 1 < my_n ? (int)my_list[1] : 0;
+        int jo_next = 0 < out_n ? (int)out_list[0] : 0;
+        for (int it = 0; it < steps; it++) {
+            const bool have = it < my_n;
+            const int j = j_next, jo = jo_next;
+            const float4 p = p_next, q = q_next, col = col_next;
+            j_next = j_after;
+            p_next = s_rec[j_next][0];
+            q_next = s_rec[j_next][1];
+            col_next = s_rec[j_next][2];
+            j_after = it + 2 < my_n ? (int)my_list[it + 2] : 0;
+            jo_next = it + 1 < out_n ? (int)out_list[it + 1] : 0;
+            const uint32_t pos = (uint32_t)(first - j);  // the reference's `contributor` after its decrement
+            const v2f d = (v2f){p.x, p.y} - pix;  // {dx, dy}
+            const float dx = d.x, dy = d.y;
+            // same evaluation order as the forward pass (and the reference): alpha must come out bit-identical
+            const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
+            const float G = exp_nonpos(power);
+            const float alpha = fminf(0.99f, q.w * G);
+            const bool live = have && pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (wave_mask(live) == 0ull) continue;  // wave-uniform
+
+            // Every lane evaluates the body.  A dead lane (pixel that does not blend this splat) runs it with
+            // alpha = 0, which leaves its state untouched without a single select: T / (1 - 0) = T, the
+            // colour behind it becomes 0 * colour + 1 * rec = rec, and every partial below is an exact zero
+            // (G and dL/dalpha are forced to 0 as well).
+            const float alpha_l = live ? alpha : 0.0f;
+            const float om = 1.f - alpha_l;
+            const float inv = __builtin_amdgcn_rcpf(om);  // v_rcp_f32, 1 ulp; exactly 1 for a dead lane
+            const float Tn = T * inv;
+            const float w = alpha_l * Tn;
+            const v2f col_rg = {col.x, col.y};
+            // `rec` is the colour accumulated behind this splat (the reference's accum_rec after its update,
+            // backward.cu:503-513)
+            // From here on only gradients are formed (compared within a tolerance, and summed by atomics in no
+            // fixed order anyway): products and sums are fused where that saves an instruction.
+            const v2f d_rg = col_rg - rec_rg;
+            float dL_dalpha = fmaf(col.z - rec_b, dpb, fmaf(d_rg.y, dp_rg.y, d_rg.x * dp_rg.x));
+            dL_dalpha = fmaf(dL_dalpha, Tn, (-T_final * inv) * bgdot);
+            dL_dalpha = live ? dL_dalpha : 0.0f;
+            const float Gl = live ? G : 0.0f;
+            const float dL_dG = q.w * dL_dalpha;
+            const v2f gd = Gl * d;  // {G dx, G dy}
+            const v2f gx = {gd.x, gd.x}, gy = {gd.y, gd.y};
+            // {dG/ddelx, dG/ddely} = -gdx * {a, b} - gdy * {b, c}
+            const v2f dG = -__builtin_elementwise_fma(gy, (v2f){q.y, q.z}, gx * (v2f){q.x, q.y});
+            const v2f v01 = (dL_dG * dG) * ddel;            // ACC_DX, ACC_DY
+            const v2f h = -0.5f * gd;
+            const v2f v23 = ((v2f){h.x, h.x} * d) * dL_dG;  // ACC_CON_A, ACC_CON_B
+            const float v4 = h.y * dy * dL_dG;              // ACC_CON_C
+            const float v5 = Gl * dL_dalpha;                // ACC_OPAC
+            const v2f v67 = w * dp_rg;                      // ACC_R, ACC_G
+            const float v8 = w * dpb;                       // ACC_B
+            // state for the next (nearer) splat: transmittance in front of this one, and the colour behind
+            // the next one = this splat blended over what was behind it (same expression the reference
+            // evaluates one step later from its last_alpha / last_color)
+            T = Tn;
+            rec_rg = __builtin_elementwise_fma((v2f){alpha_l, alpha_l}, col_rg, om * rec_rg);
+            rec_b = fmaf(alpha_l, col.z, om * rec_b);
+
+            // Sum over each quadrant's 16 pixels on the matrix unit (see the file header): nine 16x16x4 products
+            // into one accumulator, then lane 16 Q + v adds up its four result registers.
+            v4f D = {0.0f, 0.0f, 0.0f, 0.0f};
+            D = __builtin_amdgcn_mfma_f32_16x16x4f32(v01.x, sel[0], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x4f32(v01.y, sel[1], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x4f32(v23.x, sel[2], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x4f32(v23.y, sel[3], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x4f32(v4, sel[4], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x4f32(v5, sel[5], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x4f32(v67.x, sel[6], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x4f32(v67.y, sel[7], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x4f32(v8, sel[8], D, 0, 0, 0);
+            const float total = (D.x + D.y) + (D.z + D.w);
+            if (it < out_n && ocomp < ACC_USED && total != 0.0f) atomicAdd(&s_acc[jo][ocomp], total);
+        }
+        __syncthreads();
+        // Flush: 16 lanes per splat, lane c adds slot c of the splat's 64-byte accumulator row.
+        const int c = tid & 15;
+        for (int j = tid >> 4; j < nb; j += NGS_TILE_PIX / 16) {
+            if (c < ACC_USED) {
+                const float v = s_acc[j][c];
+                if (v != 0.0f)
+                    atomicAdd(acc + (size_t)__float_as_uint(s_rec[j][2].w) * NGS_ACC_STRIDE + c, v);
+            }
+        }
+    }
+}
+
+void ngs_launch_render_bwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
+                           const float4* rec, const float* bg, const float* final_T,
+                           const uint32_t* n_contrib, const float* dL_dpix, float* acc)
+{
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(cam.grid_x * cam.grid_y), dim3(NGS_TILE_PIX), 0, s, cam.W, cam.H,
+                       cam.grid_x, ranges, plist, rec, bg, final_T, n_contrib, dL_dpix, acc);
+}
