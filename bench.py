@@ -50,10 +50,12 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
         "preprocess_fwd": P * (12 + 8) + vP * (32 + 12 * c + 49),
         "scan_block_sums": 8 * ((P + 255) // 256),
         # the tile-level sort moves (tile id, Gaussian index) pairs of 8 bytes; the depth joins in the per-tile sort
-        "duplicate_with_keys": 4 * P + 8 * vP + 8 * R,
+        "duplicate_with_keys": 4 * P + 12 * vP + 8 * R,
         "radix_sort_tile_bits": tile_passes * 16 * R,
         "tile_ranges": 4 * R + 16 * T,
-        "segment_sort_depth": 4 * R + 4 * R + 4 * R + 8 * T,  # list in, depth gather, list out
+        # four 8-bit passes over P (depth bits, index) pairs (histogram read + pair read + pair write), then the
+        # gather of tile counts and rectangles into depth order
+        "depth_sort_gaussians": 4 * (4 + 8 + 8) * P + (4 + 4 + 8 + 12) * P,
         "render_fwd": 40 * R + 8 * T + 20 * W * H,
         "zero_accumulator": 64 * P,
         "render_bwd": 112 * R + 8 * T + 20 * W * H,

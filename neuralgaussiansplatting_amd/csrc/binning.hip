@@ -1,12 +1,17 @@
-// Instance binning: offsets of each Gaussian's tile instances, (tile|depth)
-// key emission and per-tile ranges of the sorted list.  Integer work, HBM
-// bound.  Results are those of the reference's InclusiveSum +
-// duplicateWithKeys + identifyTileRanges
-// (cuda_rasterizer/rasterizer_impl.cu:70-138,277-318); the schedule is not:
-// the prefix sum is two-level (per-256-Gaussian block sums come out of the
-// preprocess kernel, one workgroup scans them, the emission kernel rescans
-// inside its block), and keys are emitted by whole waves into contiguous
-// output runs instead of by one serial loop per Gaussian.
+// Instance binning: offsets of each Gaussian's tile instances, key emission
+// and per-tile ranges of the sorted list.  Integer work, HBM bound.  Results
+// are those of the reference's InclusiveSum + duplicateWithKeys + SortPairs +
+// identifyTileRanges (cuda_rasterizer/rasterizer_impl.cu:70-138,277-318); the
+// schedule is not.  The reference emits instances in index order with 64-bit
+// (tile | depth) keys and sorts all of them on all key bits.  Here the
+// GAUSSIANS are sorted by depth first (a sort of P items instead of the depth
+// half of a sort of R >= P items), instances are emitted in that order with the
+// tile id as their only key, and the stable tile-level sort then leaves every
+// tile's list in depth order, ties in index order -- the order a stable sort on
+// (tile, depth) of index-ordered instances gives.  The prefix sums are
+// two-level (block sums, one workgroup scanning them, the emission kernel
+// rescanning inside its block), and keys are emitted by whole waves into
+// contiguous output runs instead of by one serial loop per Gaussian.
 #include "ngs_common.h"
 
 #define SCAN_THREADS 1024
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
             run += v;
         }
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && misc) {  // misc == NULL: a scan of offsets only (the count has been posted before)
         if (total_wide > 0x7fffffffull) {  // the count is handed on as a signed 32-bit number
             misc[1] |= 2u;
             total = 0xffffffffu;
@@ -123,22 +128,53 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
 // so key/value stores are fully coalesced whatever the footprint sizes are.
 // Instances beyond `capacity` (a binning buffer sized from an estimate that turned out too small) are dropped and
 // flagged in misc[1]; the host then runs the stages again with a buffer that fits.
+// Gather of the per-Gaussian tile counts and rectangles into depth order, and the per-block sums of the counts in
+// that order (first level of the offset scan).  One lane per position of the order.
+__global__ __launch_bounds__(NGS_GAUSS_BLOCK) void depth_order_kernel(int P, const uint32_t* __restrict__ order,
+                                                                      const uint32_t* __restrict__ tiles,
+                                                                      const uint2* __restrict__ rect,
+                                                                      uint32_t* __restrict__ s_tiles,
+                                                                      uint2* __restrict__ s_rect,
+                                                                      uint32_t* __restrict__ s_block_sums)
+{
+    __shared__ uint32_t wave_tot[NGS_GAUSS_BLOCK / 64];
+    const int k = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
+    uint32_t t = 0;
+    if (k < P) {
+        const uint32_t g = order[k];
+        t = tiles[g];
+        s_tiles[k] = t;
+        if (t) s_rect[k] = rect[g];
+    }
+    const uint32_t ws = wave_sum_u32(t);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) s_block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// `order` == NULL: lane k emits Gaussian k; else Gaussian order[k] (rect / tiles / block_offs are then the arrays
+// in that order).
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const uint2* __restrict__ rect,
                                                                     const uint32_t* __restrict__ tiles,
                                                                     const uint32_t* __restrict__ block_offs,
+                                                                    const uint32_t* __restrict__ order,
                                                                     int grid_x, uint32_t* __restrict__ keys,
                                                                     uint32_t* __restrict__ vals, uint32_t capacity,
                                                                     uint32_t* __restrict__ misc)
 {
     __shared__ uint32_t s_incl[NGS_GAUSS_BLOCK];  // per wave: inclusive prefix of tiles within the wave
     __shared__ uint2 s_rect[NGS_GAUSS_BLOCK];
+    __shared__ uint32_t s_id[NGS_GAUSS_BLOCK];
     __shared__ uint32_t s_wave_tot[NGS_GAUSS_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + tid;
     uint32_t cnt = 0;
     if (idx < P) {
         cnt = tiles[idx];
-        if (cnt) s_rect[tid] = rect[idx];
+        if (cnt) {
+            s_rect[tid] = rect[idx];
+            s_id[tid] = order ? order[idx] : (uint32_t)idx;
+        }
     }
     const uint32_t incl = wave_incl_scan_u32(cnt, lane);
     s_incl[tid] = incl;
@@ -166,7 +202,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
         const uint32_t w = x1 - x0;
         const uint32_t ty = y0 + local / w, tx = x0 + local % w;
         keys[(size_t)wave_base + k] = ty * (uint32_t)grid_x + tx;  // the depth half of the key joins in the per-tile sort
-        vals[(size_t)wave_base + k] = (uint32_t)(blockIdx.x * NGS_GAUSS_BLOCK + wave * 64 + j);
+        vals[(size_t)wave_base + k] = s_id[wave * 64 + j];
     }
 }
 
@@ -231,12 +267,23 @@ void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* bloc
                        misc, mailbox);
 }
 
-void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
-                          int grid_x, uint32_t* keys, uint32_t* vals, int64_t capacity, uint32_t* misc)
+void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, const uint2* rect,
+                            uint32_t* s_tiles, uint2* s_rect, uint32_t* s_block_sums, uint32_t* s_block_offs)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
-    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, rect, tiles, block_offs, grid_x,
-                       keys, vals, (uint32_t)capacity, misc);
+    hipLaunchKernelGGL(depth_order_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, order, tiles, rect, s_tiles,
+                       s_rect, s_block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, s_block_sums, s_block_offs,
+                       (uint32_t*)nullptr, (unsigned long long*)nullptr);
+}
+
+void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
+                          const uint32_t* order, int grid_x, uint32_t* keys, uint32_t* vals, int64_t capacity,
+                          uint32_t* misc)
+{
+    const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, rect, tiles, block_offs, order,
+                       grid_x, keys, vals, (uint32_t)capacity, misc);
 }
 
 void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* keys, int T,

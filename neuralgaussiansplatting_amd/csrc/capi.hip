@@ -43,12 +43,12 @@ void ngs_clear_error(void) { g_err[0] = 0; }
 // a slot is reused and when the caller reads them.
 // ---------------------------------------------------------------------------
 enum {
-    ST_PREPROCESS, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SEGSORT, ST_RENDER_FWD,
+    ST_PREPROCESS, ST_SCAN, ST_DEPTHSORT, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD,
     ST_BWD_ZERO, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_SH_VIEWS, ST_LOSS, ST_ADAM_FLAT, ST_ADAM_ACTIVATED,
     ST_IDXMAP_FWD, ST_IDXMAP_BWD, ST_KNN, ST_COUNT
 };
 static const char* const g_stage_names[ST_COUNT] = {
-    "preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort_tile_bits", "tile_ranges", "segment_sort_depth",
+    "preprocess_fwd", "scan_block_sums", "depth_sort_gaussians", "duplicate_with_keys", "radix_sort_tile_bits", "tile_ranges",
     "render_fwd",
     "zero_accumulator", "render_bwd", "preprocess_bwd", "sh_gradient_from_views", "l1_ssim_loss", "adam_identity_groups",
     "adam_activated_groups", "idxmap_forward", "idxmap_backward", "knn_mean_dist2"};
@@ -291,15 +291,22 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     uint32_t* block_sums = (uint32_t*)(gb + gl.block_sums);
     uint32_t* block_offs = (uint32_t*)(gb + gl.block_offs);
     uint32_t* misc = (uint32_t*)(gb + gl.misc);
+    uint32_t* dkeys[2] = {(uint32_t*)(gb + gl.dkeys[0]), (uint32_t*)(gb + gl.dkeys[1])};
+    uint32_t* order[2] = {(uint32_t*)(gb + gl.order[0]), (uint32_t*)(gb + gl.order[1])};
+    uint32_t* s_tiles = (uint32_t*)(gb + gl.s_tiles);
+    uint2* s_rect = (uint2*)(gb + gl.s_rect);
+    uint32_t* s_block_sums = (uint32_t*)(gb + gl.s_block_sums);
+    uint32_t* s_block_offs = (uint32_t*)(gb + gl.s_block_offs);
     if (!radii) radii = (int*)(gb + gl.radii);
     const int nblocks = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
+    static_assert(32 / 8 % 2 == 0, "an even number of depth passes: the unsorted input goes to buffer 0");
 
     const int ps = prof_acquire();
     NGS_HIP(hipMemsetAsync(misc, 0, 32, st));
     prof_begin(ps, ST_PREPROCESS, st);
     ngs_launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
                               colors_precomp, cam, prefiltered, radii, rec, depth, rect, tiles, clamped,
-                              block_sums, misc);
+                              block_sums, misc, dkeys[0], order[0]);
     prof_end(ps, ST_PREPROCESS, st);
     NGS_STAGE("preprocess");
     prof_begin(ps, ST_SCAN, st);
@@ -308,6 +315,13 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     ngs_launch_scan_block_sums(st, nblocks, block_sums, block_offs, misc, mb ? mb->dev : nullptr);
     prof_end(ps, ST_SCAN, st);
     NGS_STAGE("scan");
+    // Gaussians in depth order (ties in index order: the passes are stable), then their tile counts, rectangles and
+    // instance offsets in that order.
+    prof_begin(ps, ST_DEPTHSORT, st);
+    ngs_launch_sort_tile_bits(st, nullptr, P, dkeys, order, (uint32_t*)(gb + gl.dhist), (uint32_t*)(gb + gl.dtotals), 32);
+    ngs_launch_depth_order(st, P, order[0], tiles, rect, s_tiles, s_rect, s_block_sums, s_block_offs);
+    prof_end(ps, ST_DEPTHSORT, st);
+    NGS_STAGE("depth order");
 
     // The host needs the instance count: to size the binning buffer when the caller gave no capacity (the reference
     // blocks on a device-to-host copy at the same point, rasterizer_impl.cu:281), and for the return value either
@@ -348,7 +362,8 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         uint32_t* totals = (uint32_t*)(bb + bl.totals);
         if (capacity > 0) {
             prof_begin(ps, ST_DUPLICATE, st);
-            ngs_launch_duplicate(st, P, rect, tiles, block_offs, cam.grid_x, tkeys[in_buf], vals[in_buf], capacity, misc);
+            ngs_launch_duplicate(st, P, s_rect, s_tiles, s_block_offs, order[0], cam.grid_x, tkeys[in_buf], vals[in_buf],
+                                 capacity, misc);
             prof_end(ps, ST_DUPLICATE, st);
             NGS_STAGE("duplicateWithKeys");
             prof_begin(ps, ST_SORT, st);
@@ -360,12 +375,6 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         ngs_launch_tile_ranges(st, misc, capacity, tkeys[0], T, ranges);
         prof_end(ps, ST_RANGES, st);
         NGS_STAGE("identifyTileRanges");
-        if (capacity > 0) {
-            prof_begin(ps, ST_SEGSORT, st);
-            ngs_launch_sort_segments(st, T, ranges, depth, tkeys, vals);
-            prof_end(ps, ST_SEGSORT, st);
-            NGS_STAGE("sort (depth)");
-        }
         prof_begin(ps, ST_RENDER_FWD, st);
         ngs_launch_render_fwd(st, cam, ranges, vals[0], rec, background, (float*)(ib + il.final_T),
                               (uint32_t*)(ib + il.n_contrib), out_color);

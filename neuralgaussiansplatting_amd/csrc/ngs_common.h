@@ -39,6 +39,16 @@ struct GeomLayout {
     size_t misc;       // u32   [8]  [0] total instances R, [1] error flags (1 prefiltered point culled, 2 count
                        //            beyond 2^31-1, 4 count beyond the binning buffer's capacity)
     size_t acc;        // float [P][16] gradient accumulator rows (backward)
+    // Depth order of the Gaussians (forward only): instances are emitted in this order, so that the stable
+    // tile-level sort leaves every tile's list sorted by depth.
+    size_t dkeys[2];   // u32   [P]  depth bits (all ones for a culled Gaussian), ping/pong of the radix passes
+    size_t order[2];   // u32   [P]  Gaussian indices, ping/pong; order[0] ends up sorted by (depth bits, index)
+    size_t s_tiles;    // u32   [P]  tiles touched, in depth order
+    size_t s_rect;     // uint2 [P]  packed tile rectangle, in depth order
+    size_t s_block_sums; // u32 [ceil(P/256)] tiles touched per 256 Gaussians in depth order
+    size_t s_block_offs; // u32 [ceil(P/256)] exclusive prefix of s_block_sums
+    size_t dhist;      // u32   [256 * sort_blocks(P)] histogram of the depth passes
+    size_t dtotals;    // u32   [256]
     size_t total;
 };
 
@@ -54,8 +64,7 @@ struct ImageLayout {
 // the capacity: that is all the backward pass needs from this buffer.
 struct BinLayout {
     size_t vals[2];  // u32[C] ping/pong; vals[0] (offset 0) is the sorted point list
-    size_t keys[2];  // u32[C] each: tile ids during the tile-level sort; afterwards the depth-key ping/pong of the
-                     // per-tile sort of long lists
+    size_t keys[2];  // u32[C] each: tile ids, ping/pong of the tile-level sort
     size_t hist;     // u32[256 * sort_blocks(C)] digit-major per-block histogram
     size_t totals;   // u32[256] per-digit totals
     size_t total;
@@ -81,6 +90,14 @@ static inline GeomLayout ngs_geom_layout(size_t P)
     l.block_offs = o; o = ngs_align_up(o + nb * 4);
     l.misc = o; o = ngs_align_up(o + 32);
     l.acc = o; o = ngs_align_up(o + P * NGS_ACC_STRIDE * 4);
+    for (int k = 0; k < 2; k++) { l.dkeys[k] = o; o = ngs_align_up(o + P * 4); }
+    for (int k = 0; k < 2; k++) { l.order[k] = o; o = ngs_align_up(o + P * 4); }
+    l.s_tiles = o; o = ngs_align_up(o + P * 4);
+    l.s_rect = o; o = ngs_align_up(o + P * 8);
+    l.s_block_sums = o; o = ngs_align_up(o + nb * 4);
+    l.s_block_offs = o; o = ngs_align_up(o + nb * 4);
+    l.dhist = o; o = ngs_align_up(o + ((P + NGS_SORT_TILE - 1) / NGS_SORT_TILE) * 256 * 4);
+    l.dtotals = o; o = ngs_align_up(o + 256 * 4);
     l.total = o + NGS_ALIGN;
     return l;
 }
@@ -170,11 +187,12 @@ struct ShAdamArgs {
 int ngs_set_error(const char* what, const char* detail);
 void ngs_clear_error(void);
 // preprocess_fwd.hip
+// dkeys / order: depth bits (all ones when culled) and the Gaussian's own index, the input of the depth sort
 void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* means, const float* scales, float mod,
                                const float* rots, const float* opac, const float* shs, const float* cov_pre,
                                const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* rec,
                                float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
-                               uint32_t* block_sums, uint32_t* misc);
+                               uint32_t* block_sums, uint32_t* misc, uint32_t* dkeys, uint32_t* order);
 void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const float* view, uint8_t* present);
 // binning.hip
 // mailbox: device-visible address of a 64-bit word in pinned host memory that receives (error flag << 32 | total),
@@ -184,21 +202,24 @@ void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* bloc
 // The stages between the scan and the compositing take the instance count from DEVICE memory (`count`, the word
 // the scan kernel wrote) and a capacity: launches are sized by the capacity, kernels work on min(count, capacity)
 // instances, so they can be queued before the host knows the count and never step outside the buffer.
+// ngs_launch_depth_order: from the Gaussian indices sorted by depth, the tile counts and rectangles in that order
+// and the exclusive prefix of the counts per block of 256.  ngs_launch_duplicate then emits the instances of the
+// k-th Gaussian IN DEPTH ORDER at its offset; the value of each instance is order[k].
+void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, const uint2* rect,
+                            uint32_t* s_tiles, uint2* s_rect, uint32_t* s_block_sums, uint32_t* s_block_offs);
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
-                          int grid_x, uint32_t* tile_keys, uint32_t* vals, int64_t capacity, uint32_t* misc);
+                          const uint32_t* order, int grid_x, uint32_t* tile_keys, uint32_t* vals, int64_t capacity,
+                          uint32_t* misc);
 void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* tile_keys, int T,
                             uint2* ranges);
-// radix_sort.hip: stable sort of the instances on (tile, depth) in two levels: global radix passes over the low
-// `bits` bits of 32-bit keys (tile ids) carried with 32-bit values, result in keys[0]/vals[0]; then, once the tile
-// ranges are known, a per-tile sort of vals[0] on the depth of the listed Gaussians (keys[] and vals[1] serve the
-// lists that do not fit a workgroup's registers as scratch).
+// radix_sort.hip: stable LSD radix sort of (32-bit key, 32-bit value) pairs on the low `bits` bits of the key,
+// result in keys[0]/vals[0].  It runs twice per frame: over the Gaussians' depth bits (all 32), and over the tile
+// ids of the instances emitted in that depth order -- stable, so every tile's list comes out sorted by depth.
 // ngs_sort_input_buffer returns the buffer index (0 or 1) the unsorted input must be written to.
 // `count` (device) may be NULL: the number of pairs is then `capacity` itself (the caller knows it).
 int ngs_sort_input_buffer(int bits);
 void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
                                uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits);
-void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
-                              uint32_t* const vals[2]);
 // render_fwd.hip
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,

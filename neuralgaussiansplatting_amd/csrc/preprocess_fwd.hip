@@ -90,7 +90,8 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ cov_pre, const float* __restrict__ col_pre, const NgsCamera cam,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, int prefiltered,
     int* __restrict__ radii, float4* __restrict__ rec, float* __restrict__ depth, uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint8_t* __restrict__ clamped,
-    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ misc)
+    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ misc, uint32_t* __restrict__ dkeys,
+    uint32_t* __restrict__ order)
 {
     __shared__ uint32_t wave_tot[NGS_GAUSS_BLOCK / 64];
     __shared__ float4 s_sh[EAGER ? (NGS_GAUSS_BLOCK / 64) * SH_WAVE_F4 : 1];
@@ -234,6 +235,10 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     if (idx < P) {
         radii[idx] = my_radius;
         tiles[idx] = my_tiles;
+        // input of the depth sort: the bits of a positive float order like the float; a culled Gaussian emits no
+        // instance, so its place in the order does not matter -- it goes to the end
+        dkeys[idx] = live ? __float_as_uint(view_z) : 0xffffffffu;
+        order[idx] = (uint32_t)idx;
     }
     if (EAGER) {
         // records of the wave's visible Gaussians: 4 KiB contiguous per wave (a culled Gaussian's record is never
@@ -269,7 +274,7 @@ void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* 
                                const float* rots, const float* opac, const float* shs, const float* cov_pre,
                                const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* rec,
                                float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
-                               uint32_t* block_sums, uint32_t* misc)
+                               uint32_t* block_sums, uint32_t* misc, uint32_t* dkeys, uint32_t* order)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
     const bool eager = !cov_pre && !col_pre && shs && scales && rots && D == 3 && M == 16 && (uintptr_t)shs % 16 == 0 &&
@@ -277,11 +282,11 @@ void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* 
     if (eager)
         hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales, mod, rots,
                        opac, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered, radii, rec, depth, rect, tiles, clamped,
-                       block_sums, misc);
+                       block_sums, misc, dkeys, order);
     else
         hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales,
                            mod, rots, opac, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered,
-                           radii, rec, depth, rect, tiles, clamped, block_sums, misc);
+                           radii, rec, depth, rect, tiles, clamped, block_sums, misc, dkeys, order);
 }
 
 void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const float* view, uint8_t* present)
