@@ -53,6 +53,7 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
         "duplicate_with_keys": 4 * P + 12 * vP + 8 * R,
         "radix_sort_tile_bits": tile_passes * 16 * R,
         "tile_ranges": 4 * R + 16 * T,
+        "segment_sort_depth": 4 * R + 4 * R + 4 * R + 8 * T,  # list in, depth gather, list out
         # four 8-bit passes over P (depth bits, index) pairs (histogram read + pair read + pair write), then the
         # gather of tile counts and rectangles into depth order
         "depth_sort_gaussians": 4 * (4 + 8 + 8) * P + (4 + 4 + 8 + 12) * P,

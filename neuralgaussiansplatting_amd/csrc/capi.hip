@@ -43,13 +43,13 @@ void ngs_clear_error(void) { g_err[0] = 0; }
 // a slot is reused and when the caller reads them.
 // ---------------------------------------------------------------------------
 enum {
-    ST_PREPROCESS, ST_SCAN, ST_DEPTHSORT, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD,
+    ST_PREPROCESS, ST_SCAN, ST_DEPTHSORT, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SEGSORT, ST_RENDER_FWD,
     ST_BWD_ZERO, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_SH_VIEWS, ST_LOSS, ST_ADAM_FLAT, ST_ADAM_ACTIVATED,
     ST_IDXMAP_FWD, ST_IDXMAP_BWD, ST_KNN, ST_COUNT
 };
 static const char* const g_stage_names[ST_COUNT] = {
     "preprocess_fwd", "scan_block_sums", "depth_sort_gaussians", "duplicate_with_keys", "radix_sort_tile_bits", "tile_ranges",
-    "render_fwd",
+    "segment_sort_depth", "render_fwd",
     "zero_accumulator", "render_bwd", "preprocess_bwd", "sh_gradient_from_views", "l1_ssim_loss", "adam_identity_groups",
     "adam_activated_groups", "idxmap_forward", "idxmap_backward", "knn_mean_dist2"};
 #define PROF_RING 32
@@ -250,6 +250,11 @@ extern "C" int ngs_state_layout(int P, long long R, int W, int H, size_t* geomet
     return 0;
 }
 
+// -1: the forward pass chooses where the depth order comes from; 0 / 1 force the per-tile sort / the sort of the
+// Gaussians (tests and measurements; see ngs_debug_depth_order).
+static int g_depth_order_choice = -1;
+extern "C" void ngs_debug_depth_order(int choice) { g_depth_order_choice = choice; }
+
 static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
                         void* binning_ctx, ngs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
                         const float* background, int width, int height, const float* means3D, const float* shs,
@@ -315,13 +320,6 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     ngs_launch_scan_block_sums(st, nblocks, block_sums, block_offs, misc, mb ? mb->dev : nullptr);
     prof_end(ps, ST_SCAN, st);
     NGS_STAGE("scan");
-    // Gaussians in depth order (ties in index order: the passes are stable), then their tile counts, rectangles and
-    // instance offsets in that order.
-    prof_begin(ps, ST_DEPTHSORT, st);
-    ngs_launch_sort_tile_bits(st, nullptr, P, dkeys, order, (uint32_t*)(gb + gl.dhist), (uint32_t*)(gb + gl.dtotals), 32);
-    ngs_launch_depth_order(st, P, order[0], tiles, rect, s_tiles, s_rect, s_block_sums, s_block_offs);
-    prof_end(ps, ST_DEPTHSORT, st);
-    NGS_STAGE("depth order");
 
     // The host needs the instance count: to size the binning buffer when the caller gave no capacity (the reference
     // blocks on a device-to-host copy at the same point, rasterizer_impl.cu:281), and for the return value either
@@ -351,6 +349,29 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     const int tile_bits = (int)higher_msb((uint32_t)T);
     const int in_buf = ngs_sort_input_buffer(tile_bits);
     uint2* ranges = (uint2*)(ib + il.ranges);
+    // Where the depth order comes from (both give the same lists): a sort of the P Gaussians before their instances
+    // are emitted -- 14 small launches whose cost follows P -- or a sort of every tile's list afterwards -- three
+    // launches whose cost follows the instance count and rises steeply once lists outgrow a workgroup (4096
+    // entries).  Measured on MI355X the first costs about 90 us + 48 us per million Gaussians, the second about
+    // 25 us + 14 us per million instances while lists are short.
+    bool depth_first;
+    {
+        const double inst = (double)capacity, per_tile = inst / (double)T;
+        const double by_tile = 25.0 + 14e-6 * inst * (per_tile > 1500.0 ? 1.0 + (per_tile - 1500.0) / 1500.0 : 1.0);
+        const double by_gaussian = 90.0 + 48e-6 * (double)P;
+        depth_first = by_gaussian < by_tile;
+        if (g_depth_order_choice >= 0) depth_first = g_depth_order_choice != 0;
+    }
+    if (depth_first) {
+        // Gaussians in depth order (ties in index order: the passes are stable), then their tile counts, rectangles
+        // and instance offsets in that order.
+        prof_begin(ps, ST_DEPTHSORT, st);
+        ngs_launch_sort_tile_bits(st, nullptr, P, dkeys, order, (uint32_t*)(gb + gl.dhist), (uint32_t*)(gb + gl.dtotals),
+                                  32);
+        ngs_launch_depth_order(st, P, order[0], tiles, rect, s_tiles, s_rect, s_block_sums, s_block_offs);
+        prof_end(ps, ST_DEPTHSORT, st);
+        NGS_STAGE("depth order");
+    }
     for (;;) {
         const BinLayout bl = ngs_bin_layout((size_t)capacity);
         char* bb = binning_alloc(binning_ctx, bl.total);
@@ -362,8 +383,12 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         uint32_t* totals = (uint32_t*)(bb + bl.totals);
         if (capacity > 0) {
             prof_begin(ps, ST_DUPLICATE, st);
-            ngs_launch_duplicate(st, P, s_rect, s_tiles, s_block_offs, order[0], cam.grid_x, tkeys[in_buf], vals[in_buf],
-                                 capacity, misc);
+            if (depth_first)
+                ngs_launch_duplicate(st, P, s_rect, s_tiles, s_block_offs, order[0], cam.grid_x, tkeys[in_buf],
+                                     vals[in_buf], capacity, misc);
+            else
+                ngs_launch_duplicate(st, P, rect, tiles, block_offs, nullptr, cam.grid_x, tkeys[in_buf], vals[in_buf],
+                                     capacity, misc);
             prof_end(ps, ST_DUPLICATE, st);
             NGS_STAGE("duplicateWithKeys");
             prof_begin(ps, ST_SORT, st);
@@ -375,6 +400,12 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         ngs_launch_tile_ranges(st, misc, capacity, tkeys[0], T, ranges);
         prof_end(ps, ST_RANGES, st);
         NGS_STAGE("identifyTileRanges");
+        if (capacity > 0 && !depth_first) {
+            prof_begin(ps, ST_SEGSORT, st);
+            ngs_launch_sort_segments(st, T, ranges, depth, tkeys, vals);
+            prof_end(ps, ST_SEGSORT, st);
+            NGS_STAGE("sort (depth)");
+        }
         prof_begin(ps, ST_RENDER_FWD, st);
         ngs_launch_render_fwd(st, cam, ranges, vals[0], rec, background, (float*)(ib + il.final_T),
                               (uint32_t*)(ib + il.n_contrib), out_color);

@@ -64,7 +64,8 @@ struct ImageLayout {
 // the capacity: that is all the backward pass needs from this buffer.
 struct BinLayout {
     size_t vals[2];  // u32[C] ping/pong; vals[0] (offset 0) is the sorted point list
-    size_t keys[2];  // u32[C] each: tile ids, ping/pong of the tile-level sort
+    size_t keys[2];  // u32[C] each: tile ids, ping/pong of the tile-level sort (then depth-key scratch of the per-tile
+                     // sort of long lists)
     size_t hist;     // u32[256 * sort_blocks(C)] digit-major per-block histogram
     size_t totals;   // u32[256] per-digit totals
     size_t total;
@@ -220,6 +221,10 @@ void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capaci
 int ngs_sort_input_buffer(int bits);
 void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
                                uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits);
+// Per-tile depth sort of vals[0] (lists in index order inside each tile) by the depth of the listed Gaussians;
+// keys[] and vals[1] are scratch for lists that do not fit a workgroup's registers.
+void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
+                              uint32_t* const vals[2]);
 // render_fwd.hip
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,

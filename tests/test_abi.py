@@ -45,4 +45,4 @@ def test_size_queries_and_layout_need_no_gpu():
     assert gl["grad_accumulator"] + 1000 * 64 <= g1
     assert bl["point_list"] == 0 and il["ranges"] % 256 == 0
     assert lib.ngs_last_error() == b""
-    assert lib.ngs_profile_stage_count() == 17
+    assert lib.ngs_profile_stage_count() == 18

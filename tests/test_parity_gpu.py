@@ -31,6 +31,16 @@ def dgr():
     return m
 
 
+@pytest.fixture(params=["by_tile", "by_gaussian"])
+def depth_order(request, dgr):
+    """Runs a test once per way of obtaining the depth order of the tile lists (a per-tile sort of the instances,
+    or a sort of the Gaussians before their instances are emitted); left alone, the library picks one per call."""
+    L = dgr._C.lib()
+    L.ngs_debug_depth_order(0 if request.param == "by_tile" else 1)
+    yield request.param
+    L.ngs_debug_depth_order(-1)
+
+
 def run_hip(dgr, c, dL_dpix=None, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0, prefiltered=False,
             debug=False, binning_capacity=None):
     dev = torch.device("cuda:0")
@@ -154,7 +164,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_forward_backward_matches_oracle(name, dgr, oracle):
+def test_forward_backward_matches_oracle(name, dgr, oracle, depth_order):
     c = case(**CASES[name])
     g = torch.Generator().manual_seed(99)
     dL = torch.randn(3, c["H"], c["W"], generator=g)
@@ -167,7 +177,7 @@ def test_forward_backward_matches_oracle(name, dgr, oracle):
 
 # NGS_RANDOM_CONFIGS=N widens the sweep for a soak run
 @pytest.mark.parametrize("seed", range(int(os.environ.get("NGS_RANDOM_CONFIGS", "10"))))
-def test_random_configurations(seed, dgr, oracle):
+def test_random_configurations(seed, dgr, oracle, depth_order):
     """Random image sizes (not multiples of the tile size), counts, footprints, SH degrees and eye positions."""
     rng = np.random.RandomState(1000 + seed)
     D = int(rng.randint(0, 4))
@@ -222,7 +232,7 @@ def test_nonfinite_inputs_neither_hang_nor_fault(dgr):
     assert float(torch.isfinite(res[3]).all(dim=1).float().mean()) > 0.98
 
 
-def test_more_than_65536_tiles(dgr, oracle):
+def test_more_than_65536_tiles(dgr, oracle, depth_order):
     """4112 x 4112 pixels = 257 x 257 tiles: tile ids need 17 bits, so the global part of the sort runs three radix
     passes (the other cases run one or two) and the tile coordinates use the upper range of their 16-bit fields."""
     c = case(P=2000, W=4112, H=4112, D=0, log_scale=(-4.2, -3.2), seed=41)
@@ -234,7 +244,7 @@ def test_more_than_65536_tiles(dgr, oracle):
     check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=float(c["W"] * c["H"]))
 
 
-def test_culled_and_offscreen_gaussians(dgr, oracle):
+def test_culled_and_offscreen_gaussians(dgr, oracle, depth_order):
     c = case(P=500, W=64, H=64, D=0, seed=21, eye=(0.0, 0.0, -0.6), extent=(1.5, 1.5, 1.3))
     o = oracle_forward(oracle, c)
     assert (o["radii"] == 0).sum() > 50 and (o["radii"] > 0).sum() > 50  # both kinds present
@@ -275,7 +285,7 @@ def test_scale_modifier(dgr, oracle):
     check_grads(h["grads"], oracle_backward(oracle, c, o, dL, scale_modifier=0.6), scale=64.0 * 64.0)
 
 
-def test_crowded_tiles_take_the_long_segment_path(dgr, oracle):
+def test_crowded_tiles_take_the_long_segment_path(dgr, oracle, depth_order):
     """More than 4096 instances in one tile: the per-tile depth sort leaves its in-register path."""
     c = case(P=24000, W=32, H=32, D=0, seed=37, log_scale=(-5.0, -4.0), extent=(0.5, 0.5, 1.3))
     o = oracle_forward(oracle, c)
@@ -288,7 +298,7 @@ def test_crowded_tiles_take_the_long_segment_path(dgr, oracle):
 
 
 @pytest.mark.parametrize("name", ["sh3_64x64", "big_splats", "crowded"])
-def test_presized_binning_buffer_any_capacity_same_result(name, dgr, oracle):
+def test_presized_binning_buffer_any_capacity_same_result(name, dgr, oracle, depth_order):
     """The forward pass with the binning buffer sized from an estimate before the count is known: whatever the
     estimate -- far too small (the library then repeats the stages with the right size), one short, exact,
     generous -- count, lists, ranges, image and gradients are those of the call that waits for the count."""
@@ -316,13 +326,27 @@ def test_presized_binning_buffer_any_capacity_same_result(name, dgr, oracle):
     np.testing.assert_array_equal(h["color"], ref["color"])
 
 
+def test_equal_depths_keep_index_order(dgr, oracle, depth_order):
+    """Many Gaussians at exactly the same depth (a plane facing the camera): inside a tile their order is the index
+    order, as a stable sort of index-ordered instances leaves it (rasterizer_impl.cu:88-109, 303-308)."""
+    c = case(P=3000, W=96, H=64, D=0, seed=51, eye=(0.0, 0.0, -4.0), log_scale=(-3.6, -2.8))
+    sc = c["scene"]
+    sc.means3D[:, 2] = torch.tensor([0.0, 0.25, 0.5])[torch.arange(3000) % 3]  # three planes: depths 4, 4.25, 4.5
+    o = oracle_forward(oracle, c)
+    assert len(np.unique(o["depths"][o["radii"] > 0].view(np.uint32))) <= 3
+    dL = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(2))
+    h = run_hip(dgr, c, dL_dpix=dL)
+    check_forward(o, h)
+    check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=float(c["W"] * c["H"]))
+
+
 def test_debug_mode_same_result(dgr, oracle):
     c = case(P=128, W=32, H=32, D=0, seed=23)
     o = oracle_forward(oracle, c)
     check_forward(o, run_hip(dgr, c, debug=True))
 
 
-def test_config2_100k_800x800(dgr, oracle):
+def test_config2_100k_800x800(dgr, oracle, depth_order):
     """BASELINE configuration 2 at full size, per-pixel match."""
     oracle.set_threads(8)
     try:

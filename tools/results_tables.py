@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGES = [("preprocess_fwd", "preprocess_fwd"), ("scan_block_sums", "scan_block_sums"),
           ("duplicate_with_keys", "duplicate_with_keys"), ("radix_sort_tile_bits", "radix_sort_tile_bits (2 passes)"),
-          ("tile_ranges", "tile_ranges"), ("depth_sort_gaussians", "depth_sort_gaussians"), ("render_fwd", "render_fwd"),
+          ("tile_ranges", "tile_ranges"), ("depth_sort_gaussians", "depth_sort_gaussians"), ("segment_sort_depth", "segment_sort_depth"), ("render_fwd", "render_fwd"),
           ("zero_accumulator", "zero_accumulator"), ("render_bwd", "render_bwd"), ("preprocess_bwd", "preprocess_bwd")]
 CONFIGS = {"c1": "C1 256 / 64×64 / SH0", "c2": "C2 100 k / 800×800 / SH0", "c3": "C3 300 k / 800×800 / SH3, train loop",
            "c4": "C4 3 M / 1080p / SH3", "c5": "C5 6 M / 1080p / SH3, one view"}
