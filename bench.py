@@ -69,6 +69,10 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
         # coefficients and both moments read and written once, no gradient rows
         "preprocess_bwd_sh_adam": 4 * P + vP * 105 + 92 * P + 72 * M * P,
         "adam_positions_only": 28 * 3 * P,
+        # the same kernel stepping all five parameter groups (raw parameters in, raw parameters out): per Gaussian the
+        # 11 geometry floats and 48 SH floats with both moments read and written once, no gradient at all; per
+        # rendered Gaussian its accumulator row, clamp flags and the three densification statistics
+        "preprocess_bwd_train": 4 * P + vP * (37 + 24) + 24 * 11 * P + 72 * M * P,
         "adam_activated_groups": 32 * 8 * P + 40 * P,
     }
 
@@ -107,6 +111,9 @@ def main():
                          "11 floats per Gaussian (default), or one dense all-reduce of all 59")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo lets several ranks share one GPU to rehearse the N > 1 path on a one-GPU box")
+    ap.add_argument("--unfused-train", action="store_true",
+                    help="training iterations with separate optimiser kernels (activated copies, gradients through "
+                         "memory) instead of the optimiser step inside the backward pass")
     ap.add_argument("--train-steps", type=int, default=None,
                     help="full training iterations (render + L1/D-SSIM loss + backward + exchange + Adam) timed in a "
                          "second loop for the train iters/s figure; default: min(--steps, 20), 0 to skip")
@@ -227,7 +234,8 @@ def main():
     train = None
     if train_steps > 0:
         from neuralgaussiansplatting_amd import train_step
-        trainer = train_step.GaussianTrainer(scene, dev, factored_exchange=args.exchange == "factored")
+        trainer = train_step.GaussianTrainer(scene, dev, factored_exchange=args.exchange == "factored",
+                                             fused=not args.unfused_train)
         gt = torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(4321 + rank)).to(dev)
         for _ in range(train_warmup):
             trainer.step(cam, gt, bg, tanx, tany)
@@ -256,7 +264,7 @@ def main():
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             in_sync = bool(torch.equal(hi, lo))
-        train = (t_train, train_stages, in_sync)
+        train = (t_train, train_stages, in_sync, trainer.fused)
 
     # ---- third loop: the index-map operator (nearest centre per pixel) on the same scene and view ----
     idxmap = None
@@ -369,19 +377,23 @@ def main():
             cpu = cpu_baseline(scene_cpu, synthetic.make_view(W, H, index=0, count=8), W, H, D, tanx, tany, dL)
         train_out = None
         if train is not None:
-            t_train, train_stages, in_sync = train
+            t_train, train_stages, in_sync, all_fused = train
             per_iter = {}
             fused = world == 1 and M == 16
             for name, (tot, cnt) in train_stages.items():
                 if cnt:
                     ms = tot / train_steps
-                    bkey = {"preprocess_bwd": "preprocess_bwd_sh_adam", "adam_identity_groups": "adam_positions_only"
-                            }.get(name, name) if fused else name
+                    bkey = {"preprocess_bwd": "preprocess_bwd_train" if all_fused else "preprocess_bwd_sh_adam",
+                            "adam_identity_groups": "adam_positions_only"}.get(name, name) if fused else name
                     per_iter[name] = {"ms_per_iter": round(ms, 4), "launches_per_iter": round(cnt / train_steps, 2),
                                       "GB_per_s": round(nbytes[bkey] / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
             train_out = {"iters_per_s": round(world * train_steps / t_train, 2),
                          "ms_per_iter": round(t_train / train_steps * 1e3, 4), "steps": train_steps,
-                         "what": "lr schedule + render + fused L1/D-SSIM loss + backward%s + %sfused Adam with "
+                         "what": ("lr schedule + render from the raw parameters + fused L1/D-SSIM loss + backward with "
+                                  "the activations' backward, Adam of all five parameter groups and the "
+                                  "densification statistics inside its per-Gaussian kernel, fixed random target "
+                                  "image") if all_fused else
+                                 "lr schedule + render + fused L1/D-SSIM loss + backward%s + %sfused Adam with "
                                  "activations and densification statistics, fixed random target image"
                                  % (" with the SH coefficients' Adam step inside" if fused else "",
                                     "gradient exchange + " if world > 1 else ""),

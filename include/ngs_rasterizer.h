@@ -126,6 +126,87 @@ int ngs_rasterize_backward_sh_adam(int P, int D, int M, int R, const float* back
                                    void* stream);
 
 /*
+ * Raw-parameter entry points.  The reference's extension only ever sees ACTIVATED values: its Python side applies
+ * sigmoid to the opacity, exp to the scales and normalize to the rotations on every iteration
+ * (scene/gaussian_model.py:36-43, properties at :115-127, called from gaussian_renderer/__init__.py:55-69) and
+ * autograd differentiates those operators on the way back.  A trainer that keeps the optimiser's raw parameters on
+ * the device can hand those to the library instead; the activations and their backward then run inside the
+ * per-Gaussian kernels and no activated copy or activation graph exists.
+ *
+ * ngs_rasterize_forward_raw: ngs_rasterize_forward_presized with opacities_raw [P], scales_raw [P][3] and
+ * rotations_raw [P][4] in place of the activated arrays (and no cov3D_precomp).  The image, radii and state
+ * buffers are exactly those of ngs_rasterize_forward_presized called on sigmoid(opacities_raw), exp(scales_raw)
+ * and rotations_raw / max(|rotations_raw|, 1e-12) as ngs_activate_parameters computes them.
+ *
+ * ngs_rasterize_backward_raw: ngs_rasterize_backward for a forward pass made by ngs_rasterize_forward_raw; takes
+ * the raw arrays again (plus opacities_raw, which the activated variant does not need) and returns dL_dopacity_raw,
+ * dL_dscale_raw and dL_drot_raw, the gradients wrt the RAW values: dL_dopacity * s (1 - s), dL_dscale * exp(raw),
+ * (dL_drot - q (q . dL_drot)) / |raw| with s, q the activated values.  All other outputs as ngs_rasterize_backward.
+ *
+ * ngs_rasterize_backward_train: the backward pass with torch.optim.Adam's step (scene/gaussian_model.py:255-275,
+ * train.py:124-125) of all five parameter groups fused into the per-Gaussian kernel: positions, SH coefficients,
+ * raw opacities, raw scales and raw rotations are updated IN PLACE, no gradient is written to memory.  `state`
+ * holds, per group, the parameter array (what the forward pass read), Adam's two moments, the learning rate and
+ * the 1-based count of steps this group has taken including this one (torch counts per parameter; a group whose
+ * lr is 0 keeps its values but still advances its moments).  features.lr applies to coefficient 0 of every SH row,
+ * features_rest_lr to the others (the reference's "f_dc" and "f_rest" groups).  The gradient is multiplied by
+ * grad_scale first.  When xyz_gradient_accum is not NULL the densification statistics of
+ * scene/gaussian_model.py:550-552 and train.py:115 are updated for Gaussians with radii > 0 (all three arrays are
+ * then required).  Requires SH rows of 16 coefficients and 16-byte aligned arrays.  Single-view steps only: a
+ * caller that sums gradients over views must exchange them before the optimiser runs.  Every Gaussian takes the
+ * step, rendered or not (zero gradient), as with torch.optim.Adam on dense gradients.
+ *
+ * ngs_activate_parameters: the three activations as the kernels above compute them, for callers that keep
+ * activated copies next to the raw values (any output may be NULL).
+ */
+typedef struct ngs_adam_group {
+    float* param;      /* updated in place */
+    float* exp_avg;    /* Adam's first moment, same shape */
+    float* exp_avg_sq; /* Adam's second moment, same shape */
+    double lr;
+    int step;          /* >= 1 */
+} ngs_adam_group;
+
+typedef struct ngs_train_state {
+    ngs_adam_group xyz;      /* [P][3] */
+    ngs_adam_group features; /* [P][16][3]; lr of coefficient 0 */
+    double features_rest_lr; /* lr of coefficients 1..15 */
+    ngs_adam_group opacity;  /* [P] raw */
+    ngs_adam_group scaling;  /* [P][3] raw */
+    ngs_adam_group rotation; /* [P][4] raw */
+    double beta1, beta2, eps;
+    float grad_scale;
+    float* xyz_gradient_accum; /* [P] or NULL */
+    float* denom;              /* [P] or NULL */
+    int* max_radii2D;          /* [P] or NULL */
+} ngs_train_state;
+
+int ngs_rasterize_forward_raw(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
+                              void* binning_ctx, ngs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                              const float* background, int width, int height, const float* means3D, const float* shs,
+                              const float* colors_precomp, const float* opacities_raw, const float* scales_raw,
+                              float scale_modifier, const float* rotations_raw, const float* viewmatrix,
+                              const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                              int prefiltered, float* out_color, int* radii, int debug, void* stream,
+                              int* num_rendered, long long binning_capacity);
+int ngs_rasterize_backward_raw(int P, int D, int M, int R, const float* background, int width, int height,
+                               const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities_raw, const float* scales_raw, float scale_modifier,
+                               const float* rotations_raw, const float* viewmatrix, const float* projmatrix,
+                               const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                               char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                               float* dL_dmean2D, float* dL_dconic, float* dL_dopacity_raw, float* dL_dcolor,
+                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale_raw,
+                               float* dL_drot_raw, int debug, void* stream);
+int ngs_rasterize_backward_train(int P, int D, int R, const float* background, int width, int height,
+                                 float scale_modifier, const float* viewmatrix, const float* projmatrix,
+                                 const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                                 char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                                 const ngs_train_state* state, int debug, void* stream);
+int ngs_activate_parameters(int P, const float* opacities_raw, const float* scales_raw, const float* rotations_raw,
+                            float* opacities, float* scales, float* rotations, void* stream);
+
+/*
  * ngs_rasterize_backward for callers that exchange gradients between GPUs.  No counterpart in the reference
  * (single GPU).  Arguments as ngs_rasterize_backward, plus: masked_color [P][3] receives the colour gradient with
  * the channels clamped in the forward pass zeroed (what ngs_masked_color_gradient computes from dL_dcolor) as soon

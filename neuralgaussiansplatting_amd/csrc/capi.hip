@@ -262,7 +262,7 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
                         float scale_modifier, const float* rotations, const float* cov3D_precomp,
                         const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                         float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, void* stream,
-                        int* num_rendered, long long binning_capacity)
+                        int* num_rendered, long long binning_capacity, int raw = 0)
 {
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
@@ -276,6 +276,7 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     if (!colors_precomp && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
         return fail(fn, "SH degree does not fit the coefficient count");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(fn, "need scales+rotations or cov3D_precomp");
+    if (raw && cov3D_precomp) return fail(fn, "raw parameters and cov3D_precomp exclude each other");
     const NgsCamera cam = make_camera(width, height, tan_fovx, tan_fovy, viewmatrix, projmatrix, cam_pos);
     if (cam.grid_x > 65535 || cam.grid_y > 65535) return fail(fn, "image too large");
 
@@ -309,8 +310,8 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     const int ps = prof_acquire();
     NGS_HIP(hipMemsetAsync(misc, 0, 32, st));
     prof_begin(ps, ST_PREPROCESS, st);
-    ngs_launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
-                              colors_precomp, cam, prefiltered, radii, rec, depth, rect, tiles, clamped,
+    ngs_launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, raw, shs,
+                              cov3D_precomp, colors_precomp, cam, prefiltered, radii, rec, depth, rect, tiles, clamped,
                               block_sums, misc, dkeys[0], order[0]);
     prof_end(ps, ST_PREPROCESS, st);
     NGS_STAGE("preprocess");
@@ -455,6 +456,22 @@ extern "C" int ngs_rasterize_forward_presized(ngs_alloc_fn geometry_alloc, void*
                         binning_capacity);
 }
 
+extern "C" int ngs_rasterize_forward_raw(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
+                                         void* binning_ctx, ngs_alloc_fn image_alloc, void* image_ctx, int P, int D,
+                                         int M, const float* background, int width, int height, const float* means3D,
+                                         const float* shs, const float* colors_precomp, const float* opacities_raw,
+                                         const float* scales_raw, float scale_modifier, const float* rotations_raw,
+                                         const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                         float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii,
+                                         int debug, void* stream, int* num_rendered, long long binning_capacity)
+{
+    return forward_impl("ngs_rasterize_forward_raw", geometry_alloc, geometry_ctx, binning_alloc, binning_ctx,
+                        image_alloc, image_ctx, P, D, M, background, width, height, means3D, shs, colors_precomp,
+                        opacities_raw, scales_raw, scale_modifier, rotations_raw, nullptr, viewmatrix, projmatrix,
+                        cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, stream, num_rendered,
+                        binning_capacity, 1);
+}
+
 // Optional hand-over between the two backward stages (ngs_rasterize_backward_early_color).
 struct EarlyColor {
     float* out;
@@ -470,7 +487,8 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
                          const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                          float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                          float* dL_drot, int debug, void* stream, const ShAdamArgs* sh_adam,
-                         const EarlyColor* early = nullptr)
+                         const EarlyColor* early = nullptr, const float* opacities_raw = nullptr,
+                         const GeoAdamArgs* geo = nullptr)
 {
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
@@ -478,9 +496,11 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
     if (P < 0 || P > NGS_MAX_GAUSSIANS || R < 0 || width <= 0 || height <= 0) return fail(fn, "bad sizes");
     if (P == 0) return 0;
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(fn, "missing state buffer");
-    if (!means3D || !viewmatrix || !projmatrix || !background || !dL_dpix || !dL_dmean2D || !dL_dopacity ||
-        !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+    if (!means3D || !viewmatrix || !projmatrix || !background || !dL_dpix) return fail(fn, "missing required pointer");
+    // the fused optimiser step writes no gradient
+    if (!geo && (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot))
         return fail(fn, "missing required pointer");
+    if (opacities_raw && cov3D_precomp) return fail(fn, "raw parameters and cov3D_precomp exclude each other");
     if (shs && !campos) return fail(fn, "shs given without campos");
     // the forward pass checks the same (the kernels index sh[0 .. (D+1)^2) of an M-wide row)
     if (shs && (D < 0 || D > 3 || (D + 1) * (D + 1) > M)) return fail(fn, "SH degree does not fit the coefficient count");
@@ -518,9 +538,9 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
     // scales == NULL (precomputed covariance) skips the scale/rotation gradients, shs == NULL the SH ones,
     // as in the reference (backward.cu:390-395).
     ngs_launch_preprocess_bwd(st, P, D, M, means3D, radii, shs, (const uint8_t*)(gb + gl.clamped),
-                              cov3D_precomp ? nullptr : scales, rotations, scale_modifier, cov3D_precomp, cam, acc,
-                              dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                              dL_drot, sh_adam);
+                              cov3D_precomp ? nullptr : scales, rotations, opacities_raw, scale_modifier,
+                              cov3D_precomp, cam, acc, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
+                              dL_dcov3D, dL_dsh, dL_dscale, dL_drot, sh_adam, geo);
     prof_end(ps, ST_PREPROCESS_BWD, st);
     NGS_STAGE("preprocess backward");
     return 0;
@@ -596,6 +616,88 @@ extern "C" int ngs_rasterize_backward_sh_adam(int P, int D, int M, int R, const 
                          rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
                          geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity,
                          dL_dcolor, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot, debug, stream, &a);
+}
+
+extern "C" int ngs_rasterize_backward_raw(int P, int D, int M, int R, const float* background, int width, int height,
+                                          const float* means3D, const float* shs, const float* colors_precomp,
+                                          const float* opacities_raw, const float* scales_raw, float scale_modifier,
+                                          const float* rotations_raw, const float* viewmatrix,
+                                          const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                                          const int* radii, char* geom_buffer, char* binning_buffer,
+                                          char* image_buffer, const float* dL_dpix, float* dL_dmean2D,
+                                          float* dL_dconic, float* dL_dopacity_raw, float* dL_dcolor,
+                                          float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale_raw,
+                                          float* dL_drot_raw, int debug, void* stream)
+{
+    const char* fn = "ngs_rasterize_backward_raw";
+    if (!opacities_raw || !scales_raw || !rotations_raw) {
+        g_err[0] = 0;
+        return fail(fn, "missing raw opacities, scales or rotations");
+    }
+    return backward_impl(fn, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales_raw,
+                         scale_modifier, rotations_raw, nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
+                         radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic,
+                         dL_dopacity_raw, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale_raw, dL_drot_raw, debug,
+                         stream, nullptr, nullptr, opacities_raw);
+}
+
+static AdamGroupArgs adam_group(const ngs_adam_group& g, double beta1, double beta2)
+{
+    AdamGroupArgs a;
+    a.param = g.param;
+    a.exp_avg = g.exp_avg;
+    a.exp_avg_sq = g.exp_avg_sq;
+    a.step = ngs_adam_step_size(g.lr, beta1, g.step);
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)g.step));
+    return a;
+}
+
+extern "C" int ngs_rasterize_backward_train(int P, int D, int R, const float* background, int width, int height,
+                                            float scale_modifier, const float* viewmatrix, const float* projmatrix,
+                                            const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                                            char* geom_buffer, char* binning_buffer, char* image_buffer,
+                                            const float* dL_dpix, const ngs_train_state* state, int debug, void* stream)
+{
+    const char* fn = "ngs_rasterize_backward_train";
+    g_err[0] = 0;
+    if (!state) return fail(fn, "missing optimiser state");
+    const ngs_adam_group* groups[5] = {&state->xyz, &state->features, &state->opacity, &state->scaling,
+                                       &state->rotation};
+    uintptr_t bits = 0;
+    for (const ngs_adam_group* g : groups) {
+        if (!g->param || !g->exp_avg || !g->exp_avg_sq) return fail(fn, "missing parameter or optimiser state");
+        if (!(g->lr >= 0.0) || g->step < 1) return fail(fn, "bad learning rate or step < 1");
+        bits |= (uintptr_t)g->param | (uintptr_t)g->exp_avg | (uintptr_t)g->exp_avg_sq;
+    }
+    if (!(state->features_rest_lr >= 0.0)) return fail(fn, "bad learning rate or step < 1");
+    // SH rows and quaternions move as 16-byte vectors; the other arrays are offered the same way by every allocator
+    if (bits % 16 != 0) return fail(fn, "parameters and optimiser state must be 16-byte aligned");
+    if (!(state->beta1 >= 0.0 && state->beta1 < 1.0 && state->beta2 >= 0.0 && state->beta2 < 1.0 && state->eps >= 0.0))
+        return fail(fn, "bad Adam constants");
+    const bool any_stat = state->xyz_gradient_accum || state->denom || state->max_radii2D;
+    if (any_stat && !(state->xyz_gradient_accum && state->denom && state->max_radii2D))
+        return fail(fn, "densification statistics need xyz_gradient_accum, denom and max_radii2D together");
+    ShAdamArgs a;
+    a.param = state->features.param;
+    a.exp_avg = state->features.exp_avg;
+    a.exp_avg_sq = state->features.exp_avg_sq;
+    a.step_head = ngs_adam_step_size(state->features.lr, state->beta1, state->features.step);
+    a.step_tail = ngs_adam_step_size(state->features_rest_lr, state->beta1, state->features.step);
+    a.k = ngs_adam_const(state->beta1, state->beta2, state->eps, state->features.step, state->grad_scale);
+    GeoAdamArgs geo;
+    geo.xyz = adam_group(state->xyz, state->beta1, state->beta2);
+    geo.opacity = adam_group(state->opacity, state->beta1, state->beta2);
+    geo.scaling = adam_group(state->scaling, state->beta1, state->beta2);
+    geo.rotation = adam_group(state->rotation, state->beta1, state->beta2);
+    geo.k = a.k;
+    geo.grad_accum = state->xyz_gradient_accum;
+    geo.denom = state->denom;
+    geo.max_radii = state->max_radii2D;
+    return backward_impl(fn, P, D, 16, R, background, width, height, state->xyz.param, state->features.param, nullptr,
+                         state->scaling.param, scale_modifier, state->rotation.param, nullptr, viewmatrix, projmatrix,
+                         campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, debug, stream,
+                         &a, nullptr, state->opacity.param, &geo);
 }
 
 extern "C" int ngs_masked_color_gradient(int P, const char* geom_buffer, const float* dL_dcolor, float* out,
@@ -719,6 +821,21 @@ extern "C" int ngs_adam_step_activated(int P, float* const raw[3], const float* 
     prof_end(ps, ST_ADAM_ACTIVATED, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("stage Adam (activated groups)", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int ngs_activate_parameters(int P, const float* opacities_raw, const float* scales_raw,
+                                       const float* rotations_raw, float* opacities, float* scales, float* rotations,
+                                       void* stream)
+{
+    g_err[0] = 0;
+    if (P < 0) return fail("ngs_activate_parameters", "bad size");
+    if (P == 0) return 0;
+    if ((opacities && !opacities_raw) || (scales && !scales_raw) || (rotations && !rotations_raw))
+        return fail("ngs_activate_parameters", "missing required pointer");
+    ngs_launch_activate((hipStream_t)stream, P, opacities_raw, scales_raw, rotations_raw, opacities, scales, rotations);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("stage activations", hipGetErrorString(e));
     return 0;
 }
 

@@ -181,6 +181,26 @@ struct ShAdamArgs {
     AdamConst k;
 };
 
+// Optimiser state of one further parameter group for the same kernel: step = float(lr / (1 - beta1^t)) and
+// bc2_sqrt = float(sqrt(1 - beta2^t)) with t the number of steps THIS group has taken.
+struct AdamGroupArgs {
+    float* param;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float step, bc2_sqrt;
+};
+
+// Positions, raw opacities, raw scales and raw rotations (scene/gaussian_model.py:255-261) for the fused update of
+// the per-Gaussian backward kernel; xyz.param == NULL switches it off.  grad_accum / denom / max_radii are the
+// densification statistics of scene/gaussian_model.py:550-552 and train.py:115, or NULL.
+struct GeoAdamArgs {
+    AdamGroupArgs xyz, opacity, scaling, rotation;
+    AdamConst k;  // bc2_sqrt unused: every group brings its own
+    float* grad_accum;
+    float* denom;
+    int* max_radii;
+};
+
 // ---------------------------------------------------------------------------
 // Stage launchers (each defined in the .hip file named in the comment).
 // ---------------------------------------------------------------------------
@@ -189,8 +209,9 @@ int ngs_set_error(const char* what, const char* detail);
 void ngs_clear_error(void);
 // preprocess_fwd.hip
 // dkeys / order: depth bits (all ones when culled) and the Gaussian's own index, the input of the depth sort
+// raw != 0: scales, rots and opac are the optimiser's raw parameters; the kernel applies exp / normalise / sigmoid
 void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* means, const float* scales, float mod,
-                               const float* rots, const float* opac, const float* shs, const float* cov_pre,
+                               const float* rots, const float* opac, int raw, const float* shs, const float* cov_pre,
                                const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* rec,
                                float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
                                uint32_t* block_sums, uint32_t* misc, uint32_t* dkeys, uint32_t* order);
@@ -234,12 +255,15 @@ void ngs_launch_render_bwd(hipStream_t s, const NgsCamera& cam, const uint2* ran
                            const float4* rec, const float* bg, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, float* acc);
 // preprocess_bwd.hip
+// opac_raw != NULL: scales, rots and opac_raw are the optimiser's raw parameters (the kernel applies exp /
+// normalise / sigmoid itself) and the three gradients come out wrt those raw values.  geo (needs raw parameters):
+// the kernel steps all four groups in place and writes no gradient at all; the dL_* pointers may then be NULL.
 void ngs_launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* means, const int* radii,
                                const float* shs, const uint8_t* clamped, const float* scales, const float* rots,
-                               float mod, const float* cov_pre, const NgsCamera& cam, const float* acc,
-                               float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                               const ShAdamArgs* sh_adam);
+                               const float* opac_raw, float mod, const float* cov_pre, const NgsCamera& cam,
+                               const float* acc, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                               float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                               float* dL_drot, const ShAdamArgs* sh_adam, const GeoAdamArgs* geo);
 
 // sh_views.hip: per-Gaussian colour gradient with the clamp mask applied, and the SH coefficient gradient summed
 // over V views from those masked colour gradients.
@@ -261,6 +285,8 @@ void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const 
                                const double lr[3], double beta1, double beta2, double eps, const int step[3],
                                float grad_scale, const float* dL_dmean2D, const int* radii, float* grad_accum,
                                float* denom, int* max_radii);
+void ngs_launch_activate(hipStream_t s, int P, const float* op_raw, const float* sc_raw, const float* ro_raw,
+                         float* op, float* sc, float* ro);
 
 // idxmap.hip: nearest-centre index map of the reference's second rasterizer and its backward.
 // knn.hip: mean squared distance to the three nearest neighbours (scene initialisation)
@@ -399,6 +425,22 @@ __device__ __forceinline__ float4 stream_load4(const float* p)
 __device__ __forceinline__ void stream_store4(float* p, float4 v)
 {
     __builtin_nontemporal_store((ngs_v4f){v.x, v.y, v.z, v.w}, (ngs_v4f*)p);
+}
+
+// The activations between the optimiser's raw parameters and what the rasterizer consumes
+// (scene/gaussian_model.py:36-43): sigmoid for the opacity, exp for the scales, x / max(|x|, 1e-12) for the
+// rotation, and the backward of the last one: d raw = (d act - act (act . d act)) / |raw|.
+__device__ __forceinline__ float sigmoid_act(float raw) { return 1.0f / (1.0f + expf(-raw)); }
+__device__ __forceinline__ float4 normalize_quat(float4 raw, float& len)
+{
+    len = fmaxf(sqrtf(raw.x * raw.x + raw.y * raw.y + raw.z * raw.z + raw.w * raw.w), 1e-12f);
+    return make_float4(raw.x / len, raw.y / len, raw.z / len, raw.w / len);
+}
+__device__ __forceinline__ float4 normalize_quat_backward(float4 a, float len, float4 g)
+{
+    const float dot = a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+    return make_float4((g.x - a.x * dot) / len, (g.y - a.y * dot) / len, (g.z - a.z * dot) / len,
+                       (g.w - a.w * dot) / len);
 }
 
 // bc2_sqrt is passed apart from k for callers whose parameter groups have taken different numbers of steps

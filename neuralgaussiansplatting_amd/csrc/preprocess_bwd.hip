@@ -112,16 +112,19 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const 
 }
 
 // SH_LDS: M == 16 and the SH rows travel through LDS (see the file header).
-template <bool SH_LDS>
+// RAW: scales / rots / opac_raw are the optimiser's raw parameters; only this variant carries the activations, their
+// backward and the fused optimiser step (the plain one keeps the registers and kernel arguments of the drop-in path).
+template <bool SH_LDS, bool RAW>
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
-    int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii,
+    int P, int D, int M, const float* means /* may alias geo.xyz.param */, const int* __restrict__ radii,
     const float* shs /* may alias adam.param */, const uint8_t* __restrict__ clamped,
-    const float* __restrict__ scales, const float* __restrict__ rots, float mod, const float* __restrict__ cov_pre, const NgsCamera cam,
-    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
-    const float* __restrict__ acc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
-    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
-    float* __restrict__ dL_drot, const ShAdamArgs adam)
+    const float* scales /* may alias geo.scaling.param */, const float* rots /* may alias geo.rotation.param */,
+    const float* opac_raw /* may alias geo.opacity.param */, float mod, const float* __restrict__ cov_pre,
+    const NgsCamera cam, const float* __restrict__ view, const float* __restrict__ proj,
+    const float* __restrict__ campos, const float* __restrict__ acc, float* __restrict__ dL_dmean2D,
+    float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
+    float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscale, float* __restrict__ dL_drot, const ShAdamArgs adam, const GeoAdamArgs geo)
 {
     __shared__ float s_sh[SH_LDS ? NGS_GAUSS_BLOCK * SH_ROW_LDS : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -148,40 +151,45 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         __builtin_amdgcn_wave_barrier();  // rows are wave-private and a wave's LDS operations complete in order
     }
 
-    if (in_range && !vis) {
-        dL_dmean2D[3 * i] = 0.0f; dL_dmean2D[3 * i + 1] = 0.0f; dL_dmean2D[3 * i + 2] = 0.0f;
-        if (dL_dconic) ((float4*)dL_dconic)[i] = make_float4(0, 0, 0, 0);
-        dL_dopacity[i] = 0.0f;
-        dL_dcolor[3 * i] = 0.0f; dL_dcolor[3 * i + 1] = 0.0f; dL_dcolor[3 * i + 2] = 0.0f;
-        dL_dmean3D[3 * i] = 0.0f; dL_dmean3D[3 * i + 1] = 0.0f; dL_dmean3D[3 * i + 2] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.0f;
-        if (!SH_LDS && dL_dsh)
-            for (int k = 0; k < 3 * M; k++) dL_dsh[(size_t)3 * M * i + k] = 0.0f;
-        dL_dscale[3 * i] = 0.0f; dL_dscale[3 * i + 1] = 0.0f; dL_dscale[3 * i + 2] = 0.0f;
-        ((float4*)dL_drot)[i] = make_float4(0, 0, 0, 0);
+    // Everything this Gaussian hands on: zero unless it was rendered.
+    float g_dx = 0, g_dy = 0, g_ca = 0, g_cb = 0, g_cc = 0, g_op = 0;
+    float3 g_col = make_float3(0, 0, 0), dmean = make_float3(0, 0, 0);
+    float dc[6] = {0, 0, 0, 0, 0, 0};
+    float dsc[3] = {0, 0, 0};
+    float4 dq = make_float4(0, 0, 0, 0);
+    // raw parameters (read by every Gaussian that takes an optimiser step, rendered or not)
+    const bool fused = RAW && geo.xyz.param != nullptr;
+    float mx = 0, my = 0, mz = 0, sx = 0, sy = 0, sz = 0, op_in = 0;
+    float4 q = make_float4(0, 0, 0, 0);
+    if (vis || (fused && in_range)) {
+        mx = means[3 * i]; my = means[3 * i + 1]; mz = means[3 * i + 2];
+        if (!cov_pre) {
+            sx = scales[3 * i]; sy = scales[3 * i + 1]; sz = scales[3 * i + 2];
+            q = ((const float4*)rots)[i];
+        }
+        if (RAW) op_in = opac_raw[i];
+    }
+    // raw -> activated (scene/gaussian_model.py:36-43); the raw values stay in *_in for the chain rule below
+    const float sx_in = sx, sy_in = sy, sz_in = sz;
+    const float4 q_in = q;
+    float q_len = 1.0f, op_act = 0.0f;
+    if (RAW) {
+        sx = expf(sx); sy = expf(sy); sz = expf(sz);
+        q = normalize_quat(q, q_len);
+        op_act = sigmoid_act(op_in);
     }
     if (vis) {
         const float4* row = (const float4*)(acc + i * NGS_ACC_STRIDE);
         const float4 r0 = row[0], r1 = row[1];
         const float r2 = acc[i * NGS_ACC_STRIDE + 8];
-        const float g_dx = r0.x, g_dy = r0.y, g_ca = r0.z, g_cb = r0.w, g_cc = r1.x, g_op = r1.y;
-        const float3 g_col = make_float3(r1.z, r1.w, r2);
-        dL_dmean2D[3 * i] = g_dx; dL_dmean2D[3 * i + 1] = g_dy; dL_dmean2D[3 * i + 2] = 0.0f;
-        if (dL_dconic) ((float4*)dL_dconic)[i] = make_float4(g_ca, g_cb, 0.0f, g_cc);
-        dL_dopacity[i] = g_op;
-        dL_dcolor[3 * i] = g_col.x; dL_dcolor[3 * i + 1] = g_col.y; dL_dcolor[3 * i + 2] = g_col.z;
+        g_dx = r0.x; g_dy = r0.y; g_ca = r0.z; g_cb = r0.w; g_cc = r1.x; g_op = r1.y;
+        g_col = make_float3(r1.z, r1.w, r2);
 
-        const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
-        float sx = 0, sy = 0, sz = 0;
-        float4 q = make_float4(0, 0, 0, 0);
         float c6[6];
         if (cov_pre) {
 #pragma unroll
             for (int k = 0; k < 6; k++) c6[k] = cov_pre[6 * i + k];
         } else {
-            sx = scales[3 * i]; sy = scales[3 * i + 1]; sz = scales[3 * i + 2];
-            q = ((const float4*)rots)[i];
             cov3d_from_scale_rot(sx, sy, sz, mod, q.x, q.y, q.z, q.w, c6);
         }
 
@@ -196,7 +204,6 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         const Mat3& T = k.T;
         const Mat3& V = k.V;
         const Mat3& Wm = k.W;
-        float dc[6];
         if (d2inv != 0) {
             dL_da = d2inv * (-c * c * g_ca + 2 * b * c * g_cb + (denom - a * c) * g_cc);
             dL_dc = d2inv * (-a * a * g_cc + 2 * a * b * g_cb + (denom - a * c) * g_ca);
@@ -210,12 +217,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
                     2 * T.c[1][0] * T.c[1][2] * dL_dc;
             dc[4] = 2 * T.c[0][2] * T.c[0][1] * dL_da + (T.c[0][1] * T.c[1][2] + T.c[0][2] * T.c[1][1]) * dL_db +
                     2 * T.c[1][1] * T.c[1][2] * dL_dc;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 6; j++) dc[j] = 0;
         }
-#pragma unroll
-        for (int j = 0; j < 6; j++) dL_dcov3D[6 * i + j] = dc[j];
         float t0[3], t1[3];  // rows 0 and 1 of T * Vrk
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -238,9 +240,9 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         const float dty = ymul * -fy * tz2 * dJ12;
         const float dtz =
             -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * k.t.x) * tz3 * dJ02 + (2 * fy * k.t.y) * tz3 * dJ12;
-        float3 dmean = make_float3(view[0] * dtx + view[1] * dty + view[2] * dtz,
-                                   view[4] * dtx + view[5] * dty + view[6] * dtz,
-                                   view[8] * dtx + view[9] * dty + view[10] * dtz);
+        dmean = make_float3(view[0] * dtx + view[1] * dty + view[2] * dtz,
+                            view[4] * dtx + view[5] * dty + view[6] * dtz,
+                            view[8] * dtx + view[9] * dty + view[10] * dtz);
 
         // ---- perspective projection backward (backward.cu:372-387) ----
         const float4 mh = xform44(mx, my, mz, proj);
@@ -260,7 +262,6 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
             const float3 ds = sh_backward(D, M, make_float3(mx, my, mz), campos, sh_in, clamped[i], g_col, sh_out);
             dmean.x += ds.x; dmean.y += ds.y; dmean.z += ds.z;
         }
-        dL_dmean3D[3 * i] = dmean.x; dL_dmean3D[3 * i + 1] = dmean.y; dL_dmean3D[3 * i + 2] = dmean.z;
 
         // ---- scale / rotation backward (backward.cu:278-341) ----
         if (scales) {
@@ -280,21 +281,87 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
             const Mat3 dM = m3_mul(M2, dSig);
             const Mat3 Rt = m3_tr(R);
             Mat3 dMt = m3_tr(dM);
-            dL_dscale[3 * i] = Rt.c[0][0] * dMt.c[0][0] + Rt.c[0][1] * dMt.c[0][1] + Rt.c[0][2] * dMt.c[0][2];
-            dL_dscale[3 * i + 1] = Rt.c[1][0] * dMt.c[1][0] + Rt.c[1][1] * dMt.c[1][1] + Rt.c[1][2] * dMt.c[1][2];
-            dL_dscale[3 * i + 2] = Rt.c[2][0] * dMt.c[2][0] + Rt.c[2][1] * dMt.c[2][1] + Rt.c[2][2] * dMt.c[2][2];
+            dsc[0] = Rt.c[0][0] * dMt.c[0][0] + Rt.c[0][1] * dMt.c[0][1] + Rt.c[0][2] * dMt.c[0][2];
+            dsc[1] = Rt.c[1][0] * dMt.c[1][0] + Rt.c[1][1] * dMt.c[1][1] + Rt.c[1][2] * dMt.c[1][2];
+            dsc[2] = Rt.c[2][0] * dMt.c[2][0] + Rt.c[2][1] * dMt.c[2][1] + Rt.c[2][2] * dMt.c[2][2];
 #pragma unroll
             for (int e = 0; e < 3; e++) { dMt.c[0][e] *= s0; dMt.c[1][e] *= s1; dMt.c[2][e] *= s2; }
-            float4 dq;
             dq.x = 2 * z * (dMt.c[0][1] - dMt.c[1][0]) + 2 * y * (dMt.c[2][0] - dMt.c[0][2]) + 2 * x * (dMt.c[1][2] - dMt.c[2][1]);
             dq.y = 2 * y * (dMt.c[1][0] + dMt.c[0][1]) + 2 * z * (dMt.c[2][0] + dMt.c[0][2]) + 2 * r * (dMt.c[1][2] - dMt.c[2][1]) - 4 * x * (dMt.c[2][2] + dMt.c[1][1]);
             dq.z = 2 * x * (dMt.c[1][0] + dMt.c[0][1]) + 2 * r * (dMt.c[2][0] - dMt.c[0][2]) + 2 * z * (dMt.c[1][2] + dMt.c[2][1]) - 4 * y * (dMt.c[2][2] + dMt.c[0][0]);
             dq.w = 2 * r * (dMt.c[0][1] - dMt.c[1][0]) + 2 * x * (dMt.c[2][0] + dMt.c[0][2]) + 2 * y * (dMt.c[1][2] + dMt.c[2][1]) - 4 * z * (dMt.c[1][1] + dMt.c[0][0]);
-            ((float4*)dL_drot)[i] = dq;
-        } else {
-            dL_dscale[3 * i] = 0.0f; dL_dscale[3 * i + 1] = 0.0f; dL_dscale[3 * i + 2] = 0.0f;
-            ((float4*)dL_drot)[i] = make_float4(0, 0, 0, 0);
         }
+    }
+
+    if (fused && in_range) {
+        // Fused optimiser step of the positions, raw opacities, raw scales and raw rotations: the activations'
+        // backward (sigmoid / exp / normalise) and Adam, with the gradients still in registers.  A Gaussian that was
+        // not rendered steps on a zero gradient like every other (its moments decay, its parameters coast).
+        const AdamConst& ak = geo.k;
+        {
+            float p[3] = {mx, my, mz}, g[3] = {dmean.x, dmean.y, dmean.z};
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                float m = geo.xyz.exp_avg[3 * i + e], v = geo.xyz.exp_avg_sq[3 * i + e];
+                geo.xyz.param[3 * i + e] = adam_update(p[e], g[e] * ak.grad_scale, m, v, geo.xyz.step, geo.xyz.bc2_sqrt, ak);
+                geo.xyz.exp_avg[3 * i + e] = m;
+                geo.xyz.exp_avg_sq[3 * i + e] = v;
+            }
+        }
+        {
+            const float g = (g_op * ak.grad_scale) * ((1.0f - op_act) * op_act);
+            float m = geo.opacity.exp_avg[i], v = geo.opacity.exp_avg_sq[i];
+            geo.opacity.param[i] = adam_update(op_in, g, m, v, geo.opacity.step, geo.opacity.bc2_sqrt, ak);
+            geo.opacity.exp_avg[i] = m;
+            geo.opacity.exp_avg_sq[i] = v;
+        }
+        {
+            const float p[3] = {sx_in, sy_in, sz_in}, a[3] = {sx, sy, sz};
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                const float g = (dsc[e] * ak.grad_scale) * a[e];
+                float m = geo.scaling.exp_avg[3 * i + e], v = geo.scaling.exp_avg_sq[3 * i + e];
+                geo.scaling.param[3 * i + e] = adam_update(p[e], g, m, v, geo.scaling.step, geo.scaling.bc2_sqrt, ak);
+                geo.scaling.exp_avg[3 * i + e] = m;
+                geo.scaling.exp_avg_sq[3 * i + e] = v;
+            }
+        }
+        {
+            const float4 g = make_float4(dq.x * ak.grad_scale, dq.y * ak.grad_scale, dq.z * ak.grad_scale,
+                                         dq.w * ak.grad_scale);
+            const float4 gr = normalize_quat_backward(q, q_len, g);
+            float4 m = ((const float4*)geo.rotation.exp_avg)[i], v = ((const float4*)geo.rotation.exp_avg_sq)[i];
+            float4 nr;
+            nr.x = adam_update(q_in.x, gr.x, m.x, v.x, geo.rotation.step, geo.rotation.bc2_sqrt, ak);
+            nr.y = adam_update(q_in.y, gr.y, m.y, v.y, geo.rotation.step, geo.rotation.bc2_sqrt, ak);
+            nr.z = adam_update(q_in.z, gr.z, m.z, v.z, geo.rotation.step, geo.rotation.bc2_sqrt, ak);
+            nr.w = adam_update(q_in.w, gr.w, m.w, v.w, geo.rotation.step, geo.rotation.bc2_sqrt, ak);
+            ((float4*)geo.rotation.param)[i] = nr;
+            ((float4*)geo.rotation.exp_avg)[i] = m;
+            ((float4*)geo.rotation.exp_avg_sq)[i] = v;
+        }
+        if (geo.grad_accum && vis) {  // densification statistics (train.py:115, scene/gaussian_model.py:550-552)
+            geo.grad_accum[i] += sqrtf(g_dx * g_dx + g_dy * g_dy);
+            geo.denom[i] += 1.0f;
+            geo.max_radii[i] = max(geo.max_radii[i], radii[idx]);
+        }
+    } else if (in_range) {
+        if (RAW) {  // gradients wrt the raw parameters: the activations' backward
+            g_op = g_op * ((1.0f - op_act) * op_act);
+            dsc[0] = dsc[0] * sx; dsc[1] = dsc[1] * sy; dsc[2] = dsc[2] * sz;
+            dq = normalize_quat_backward(q, q_len, dq);
+        }
+        dL_dmean2D[3 * i] = g_dx; dL_dmean2D[3 * i + 1] = g_dy; dL_dmean2D[3 * i + 2] = 0.0f;
+        if (dL_dconic) ((float4*)dL_dconic)[i] = make_float4(g_ca, g_cb, 0.0f, g_cc);
+        dL_dopacity[i] = g_op;
+        dL_dcolor[3 * i] = g_col.x; dL_dcolor[3 * i + 1] = g_col.y; dL_dcolor[3 * i + 2] = g_col.z;
+        dL_dmean3D[3 * i] = dmean.x; dL_dmean3D[3 * i + 1] = dmean.y; dL_dmean3D[3 * i + 2] = dmean.z;
+#pragma unroll
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = dc[k];
+        if (!SH_LDS && dL_dsh && !vis)
+            for (int k = 0; k < 3 * M; k++) dL_dsh[(size_t)3 * M * i + k] = 0.0f;
+        dL_dscale[3 * i] = dsc[0]; dL_dscale[3 * i + 1] = dsc[1]; dL_dscale[3 * i + 2] = dsc[2];
+        ((float4*)dL_drot)[i] = dq;
     }
 
     if (SH_LDS && adam.param) {
@@ -339,25 +406,29 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
 
 void ngs_launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* means, const int* radii,
                                const float* shs, const uint8_t* clamped, const float* scales, const float* rots,
-                               float mod, const float* cov_pre, const NgsCamera& cam, const float* acc,
-                               float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                               const ShAdamArgs* sh_adam)
+                               const float* opac_raw, float mod, const float* cov_pre, const NgsCamera& cam,
+                               const float* acc, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                               float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                               float* dL_drot, const ShAdamArgs* sh_adam, const GeoAdamArgs* geo_adam)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
     ShAdamArgs adam;
     memset(&adam, 0, sizeof adam);
     if (sh_adam) adam = *sh_adam;  // the caller has checked that the LDS path below applies
+    GeoAdamArgs geo;
+    memset(&geo, 0, sizeof geo);
+    if (geo_adam) geo = *geo_adam;  // the caller has checked that the parameters are the raw ones
     // LDS staging needs 16-byte aligned 192-byte rows
     const bool lds = shs && M == 16 && ((uintptr_t)shs % 16 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
-    if (lds)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, radii,
-                           shs, clamped, scales, rots, mod, cov_pre, cam, cam.view, cam.proj, cam.campos, acc,
-                           dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                           dL_drot, adam);
-    else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, radii,
-                           shs, clamped, scales, rots, mod, cov_pre, cam, cam.view, cam.proj, cam.campos, acc,
-                           dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                           dL_drot, adam);
+#define NGS_PRE_BWD(LDS, RAWP)                                                                                        \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<LDS, RAWP>), dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means,      \
+                       radii, shs, clamped, scales, rots, opac_raw, mod, cov_pre, cam, cam.view, cam.proj, cam.campos, \
+                       acc, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,   \
+                       dL_drot, adam, geo)
+    if (opac_raw) {
+        if (lds) NGS_PRE_BWD(true, true); else NGS_PRE_BWD(false, true);
+    } else {
+        if (lds) NGS_PRE_BWD(true, false); else NGS_PRE_BWD(false, false);
+    }
+#undef NGS_PRE_BWD
 }

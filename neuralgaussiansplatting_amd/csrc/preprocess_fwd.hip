@@ -86,7 +86,7 @@ __device__ __forceinline__ float3 sh_to_rgb_last8(float3 res, const float3* c8, 
 template <bool EAGER>
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float mod,
-    const float* __restrict__ rots, const float* __restrict__ opac, const float* __restrict__ shs,
+    const float* __restrict__ rots, const float* __restrict__ opac, int raw, const float* __restrict__ shs,
     const float* __restrict__ cov_pre, const float* __restrict__ col_pre, const NgsCamera cam,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, int prefiltered,
     int* __restrict__ radii, float4* __restrict__ rec, float* __restrict__ depth, uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint8_t* __restrict__ clamped,
@@ -132,6 +132,12 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
             e_q = ((const float4*)rots)[idx];
             e_s0 = scales[3 * idx]; e_s1 = scales[3 * idx + 1]; e_s2 = scales[3 * idx + 2];
             e_op = opac[idx];
+            if (raw) {  // the optimiser's raw parameters: activations of scene/gaussian_model.py:36-43
+                float len;
+                e_q = normalize_quat(e_q, len);
+                e_s0 = expf(e_s0); e_s1 = expf(e_s1); e_s2 = expf(e_s2);
+                e_op = sigmoid_act(e_op);
+            }
         }
         const float3 pv = xform43(px, py, pz, view);
         view_z = pv.z;
@@ -153,8 +159,14 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
             } else {
                 // element loads: this kernel also serves quaternion arrays that are not 16-byte aligned
                 const float* q = rots + 4 * (size_t)idx;
-                cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], mod, q[0], q[1], q[2],
-                                     q[3], c6);
+                float4 qv = make_float4(q[0], q[1], q[2], q[3]);
+                float s0 = scales[3 * idx], s1 = scales[3 * idx + 1], s2 = scales[3 * idx + 2];
+                if (raw) {
+                    float len;
+                    qv = normalize_quat(qv, len);
+                    s0 = expf(s0); s1 = expf(s1); s2 = expf(s2);
+                }
+                cov3d_from_scale_rot(s0, s1, s2, mod, qv.x, qv.y, qv.z, qv.w, c6);
             }
             const Cov2D k = cov2d_eval(px, py, pz, cam, view, c6);
             const float det = k.a * k.c - k.b * k.b;
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
         }
         float4* r = rec + 4 * (size_t)idx;
         r[0] = make_float4(ix, iy, con_x, con_y);
-        r[1] = make_float4(con_z, opac[idx], col.x, col.y);
+        r[1] = make_float4(con_z, raw ? sigmoid_act(opac[idx]) : opac[idx], col.x, col.y);
         r[2] = make_float4(col.z, 0.0f, 0.0f, 0.0f);
     }
     if (live) {
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* _
 }
 
 void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* means, const float* scales, float mod,
-                               const float* rots, const float* opac, const float* shs, const float* cov_pre,
+                               const float* rots, const float* opac, int raw, const float* shs, const float* cov_pre,
                                const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* rec,
                                float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
                                uint32_t* block_sums, uint32_t* misc, uint32_t* dkeys, uint32_t* order)
@@ -281,11 +293,11 @@ void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* 
                        (uintptr_t)rots % 16 == 0;
     if (eager)
         hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales, mod, rots,
-                       opac, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered, radii, rec, depth, rect, tiles, clamped,
+                       opac, raw, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered, radii, rec, depth, rect, tiles, clamped,
                        block_sums, misc, dkeys, order);
     else
         hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales,
-                           mod, rots, opac, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered,
+                           mod, rots, opac, raw, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered,
                            radii, rec, depth, rect, tiles, clamped, block_sums, misc, dkeys, order);
 }
 

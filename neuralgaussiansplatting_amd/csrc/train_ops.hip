@@ -352,14 +352,14 @@ __global__ __launch_bounds__(256) void adam_activated_kernel(int P, ActivatedGro
     const size_t i = (size_t)idx;
     {   // opacity = sigmoid(raw): d raw = d act * act * (1 - act)
         const float raw = op.raw[i];
-        const float act = 1.0f / (1.0f + expf(-raw));
+        const float act = sigmoid_act(raw);
         const float g = (op.grad[i] * k.grad_scale) * ((1.0f - act) * act);
         float m = op.exp_avg[i], v = op.exp_avg_sq[i];
         const float nr = adam_update(raw, g, m, v, op.step, op.bc2_sqrt, k);
         op.raw[i] = nr;
         op.exp_avg[i] = m;
         op.exp_avg_sq[i] = v;
-        op.activated[i] = 1.0f / (1.0f + expf(-nr));
+        op.activated[i] = sigmoid_act(nr);
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {  // scale = exp(raw): d raw = d act * act
@@ -377,11 +377,9 @@ __global__ __launch_bounds__(256) void adam_activated_kernel(int P, ActivatedGro
         const float4 raw = ((const float4*)ro.raw)[i];
         float4 g = ((const float4*)ro.grad)[i];
         g.x *= k.grad_scale; g.y *= k.grad_scale; g.z *= k.grad_scale; g.w *= k.grad_scale;
-        const float len = fmaxf(sqrtf(raw.x * raw.x + raw.y * raw.y + raw.z * raw.z + raw.w * raw.w), 1e-12f);
-        const float4 a = make_float4(raw.x / len, raw.y / len, raw.z / len, raw.w / len);
-        const float dot = a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
-        const float4 gr = make_float4((g.x - a.x * dot) / len, (g.y - a.y * dot) / len, (g.z - a.z * dot) / len,
-                                      (g.w - a.w * dot) / len);
+        float len;
+        const float4 a = normalize_quat(raw, len);
+        const float4 gr = normalize_quat_backward(a, len, g);
         float4 m = ((const float4*)ro.exp_avg)[i], v = ((const float4*)ro.exp_avg_sq)[i];
         float4 nr;
         nr.x = adam_update(raw.x, gr.x, m.x, v.x, ro.step, ro.bc2_sqrt, k);
@@ -391,8 +389,8 @@ __global__ __launch_bounds__(256) void adam_activated_kernel(int P, ActivatedGro
         ((float4*)ro.raw)[i] = nr;
         ((float4*)ro.exp_avg)[i] = m;
         ((float4*)ro.exp_avg_sq)[i] = v;
-        const float nl = fmaxf(sqrtf(nr.x * nr.x + nr.y * nr.y + nr.z * nr.z + nr.w * nr.w), 1e-12f);
-        ((float4*)ro.activated)[i] = make_float4(nr.x / nl, nr.y / nl, nr.z / nl, nr.w / nl);
+        float nl;
+        ((float4*)ro.activated)[i] = normalize_quat(nr, nl);
     }
     if (grad_accum) {
         const int r = radii[i];
@@ -412,10 +410,10 @@ __global__ __launch_bounds__(256) void adam_activated_kernel(int P, ActivatedGro
 __device__ __forceinline__ void adam_opacity_elem(float& raw, float g, float& m, float& v, float& act,
                                                   const ActivatedGroup& op, const AdamConst& k)
 {
-    const float a = 1.0f / (1.0f + expf(-raw));
+    const float a = sigmoid_act(raw);
     const float gr = (g * k.grad_scale) * ((1.0f - a) * a);
     raw = adam_update(raw, gr, m, v, op.step, op.bc2_sqrt, k);
-    act = 1.0f / (1.0f + expf(-raw));
+    act = sigmoid_act(raw);
 }
 __device__ __forceinline__ void adam_scale_elem(float& raw, float g, float& m, float& v, float& act,
                                                 const ActivatedGroup& sc, const AdamConst& k)
@@ -470,11 +468,9 @@ __global__ __launch_bounds__(256) void adam_activated_vec_kernel(int P, Activate
         const float4 raw = ((const float4*)ro.raw)[i];
         float4 g = ((const float4*)ro.grad)[i];
         g.x *= k.grad_scale; g.y *= k.grad_scale; g.z *= k.grad_scale; g.w *= k.grad_scale;
-        const float len = fmaxf(sqrtf(raw.x * raw.x + raw.y * raw.y + raw.z * raw.z + raw.w * raw.w), 1e-12f);
-        const float4 a = make_float4(raw.x / len, raw.y / len, raw.z / len, raw.w / len);
-        const float dot = a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
-        const float4 gr = make_float4((g.x - a.x * dot) / len, (g.y - a.y * dot) / len, (g.z - a.z * dot) / len,
-                                      (g.w - a.w * dot) / len);
+        float len;
+        const float4 a = normalize_quat(raw, len);
+        const float4 gr = normalize_quat_backward(a, len, g);
         float4 m = ((const float4*)ro.exp_avg)[i], v = ((const float4*)ro.exp_avg_sq)[i];
         float4 nr;
         nr.x = adam_update(raw.x, gr.x, m.x, v.x, ro.step, ro.bc2_sqrt, k);
@@ -484,8 +480,8 @@ __global__ __launch_bounds__(256) void adam_activated_vec_kernel(int P, Activate
         ((float4*)ro.raw)[i] = nr;
         ((float4*)ro.exp_avg)[i] = m;
         ((float4*)ro.exp_avg_sq)[i] = v;
-        const float nl = fmaxf(sqrtf(nr.x * nr.x + nr.y * nr.y + nr.z * nr.z + nr.w * nr.w), 1e-12f);
-        ((float4*)ro.activated)[i] = make_float4(nr.x / nl, nr.y / nl, nr.z / nl, nr.w / nl);
+        float nl;
+        ((float4*)ro.activated)[i] = normalize_quat(nr, nl);
     }
     if (grad_accum) {
         const int r = radii[i];
@@ -495,6 +491,28 @@ __global__ __launch_bounds__(256) void adam_activated_vec_kernel(int P, Activate
             denom[i] += 1.0f;
             max_radii[i] = max(max_radii[i], r);
         }
+    }
+}
+
+// The three activations on their own (any output may be NULL); element accesses, no alignment needed.
+__global__ __launch_bounds__(256) void activate_kernel(int P, const float* __restrict__ op_raw,
+                                                       const float* __restrict__ sc_raw,
+                                                       const float* __restrict__ ro_raw, float* __restrict__ op,
+                                                       float* __restrict__ sc, float* __restrict__ ro)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const size_t i = (size_t)idx;
+    if (op) op[i] = sigmoid_act(op_raw[i]);
+    if (sc) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) sc[3 * i + c] = expf(sc_raw[3 * i + c]);
+    }
+    if (ro) {
+        float len;
+        const float4 a = normalize_quat(make_float4(ro_raw[4 * i], ro_raw[4 * i + 1], ro_raw[4 * i + 2],
+                                                    ro_raw[4 * i + 3]), len);
+        ro[4 * i] = a.x; ro[4 * i + 1] = a.y; ro[4 * i + 2] = a.z; ro[4 * i + 3] = a.w;
     }
 }
 
@@ -578,4 +596,10 @@ void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const 
         hipLaunchKernelGGL(adam_activated_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g[0], g[1], g[2],
                            ngs_adam_const(beta1, beta2, eps, step[0], grad_scale), dL_dmean2D, radii, grad_accum,
                            denom, max_radii);
+}
+
+void ngs_launch_activate(hipStream_t s, int P, const float* op_raw, const float* sc_raw, const float* ro_raw,
+                         float* op, float* sc, float* ro)
+{
+    hipLaunchKernelGGL(activate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, op_raw, sc_raw, ro_raw, op, sc, ro);
 }

@@ -36,6 +36,10 @@ def lib():
         L.ngs_rasterize_forward_presized.restype = ctypes.c_int
         L.ngs_rasterize_backward.restype = ctypes.c_int
         L.ngs_rasterize_backward_sh_adam.restype = ctypes.c_int
+        L.ngs_rasterize_forward_raw.restype = ctypes.c_int
+        L.ngs_rasterize_backward_raw.restype = ctypes.c_int
+        L.ngs_rasterize_backward_train.restype = ctypes.c_int
+        L.ngs_activate_parameters.restype = ctypes.c_int
         L.ngs_mark_visible.restype = ctypes.c_int
         L.ngs_state_layout.restype = ctypes.c_int
         L.ngs_masked_color_gradient.restype = ctypes.c_int
@@ -115,6 +119,24 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug):
     """-> (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)"""
+    return _forward(False, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                    viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                    prefiltered, debug)
+
+
+def rasterize_gaussians_raw(background, means3D, colors, opacity_raw, scales_raw, rotations_raw, scale_modifier,
+                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                            prefiltered, debug):
+    """``rasterize_gaussians`` on the optimiser's raw parameters: sigmoid / exp / normalize
+    (scene/gaussian_model.py:36-43) are applied inside the library.  Same return tuple."""
+    return _forward(True, background, means3D, colors, opacity_raw, scales_raw, rotations_raw, scale_modifier,
+                    torch.empty(0), viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                    campos, prefiltered, debug)
+
+
+def _forward(raw, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+             viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+             prefiltered, debug):
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D)
@@ -137,13 +159,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         M = sh.size(1) if sh.numel() != 0 else 0
-        with torch.cuda.device(dev):
-            _check(lib().ngs_rasterize_forward_presized(
-                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), _ptr(background), W, H,
+        head = (geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), _ptr(background), W, H,
                 _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), ctypes.c_float(scale_modifier),
-                _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
-                ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy), int(bool(prefiltered)), _ptr(out_color),
-                _ptr(radii), int(bool(debug)), _stream(dev), ctypes.byref(rendered), ctypes.c_longlong(capacity)))
+                _ptr(rotations))
+        tail = (_ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy),
+                int(bool(prefiltered)), _ptr(out_color), _ptr(radii), int(bool(debug)), _stream(dev),
+                ctypes.byref(rendered), ctypes.c_longlong(capacity))
+        with torch.cuda.device(dev):
+            if raw:
+                _check(lib().ngs_rasterize_forward_raw(*head, *tail))
+            else:
+                _check(lib().ngs_rasterize_forward_presized(*head, _ptr(cov3D_precomp), *tail))
         if len(_instance_hint) > 256:
             _instance_hint.clear()
         _instance_hint[hint_key] = (P, rendered.value)
@@ -251,6 +277,120 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 int(bool(debug)), _stream(dev)))
     res = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     return res + (dL_dconic,) if return_conic else res
+
+
+def rasterize_gaussians_backward_raw(background, means3D, radii, colors, opacity_raw, scales_raw, rotations_raw,
+                                     scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
+                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, out=None):
+    """Backward of ``rasterize_gaussians_raw``.  Same return tuple as ``rasterize_gaussians_backward``, with
+    dL_dopacity, dL_dscales and dL_drotations taken wrt the RAW values (the activations' backward is applied
+    inside the library)."""
+    _require_gpu(means3D)
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    means3D, colors, opacity_raw, scales_raw, rotations_raw, sh, dL_dout_color = (
+        _f32(x, dev) for x in (means3D, colors, opacity_raw, scales_raw, rotations_raw, sh, dL_dout_color))
+    background, viewmatrix, projmatrix, campos = (_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
+    out = out or {}
+    shapes = dict(dL_dmeans2D=(P, 3), dL_dcolors=(P, NUM_CHANNELS), dL_dopacity=(P, 1), dL_dmeans3D=(P, 3),
+                  dL_dcov3D=(P, 6), dL_dsh=(P, M, 3), dL_dscales=(P, 3), dL_drotations=(P, 4))
+    g = {}
+    for name, shape in shapes.items():
+        t = out.get(name)
+        if t is None:
+            t = (torch.empty if P != 0 else torch.zeros)(shape, dtype=torch.float32, device=dev)
+        elif t.numel() != torch.Size(shape).numel() or t.dtype != torch.float32 or t.device != dev or \
+                not t.is_contiguous():
+            raise RuntimeError("out[%r] must be a contiguous float32 tensor shaped %s on %s" % (name, shape, dev))
+        g[name] = t.view(shape)
+    if P != 0:
+        with torch.cuda.device(dev):
+            _check(lib().ngs_rasterize_backward_raw(
+                P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                _ptr(opacity_raw), _ptr(scales_raw), ctypes.c_float(scale_modifier), _ptr(rotations_raw),
+                _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy),
+                _ptr(radii.contiguous()), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                _ptr(dL_dout_color), _ptr(g["dL_dmeans2D"]), ctypes.c_void_p(0), _ptr(g["dL_dopacity"]),
+                _ptr(g["dL_dcolors"]), _ptr(g["dL_dmeans3D"]), _ptr(g["dL_dcov3D"]), _ptr(g["dL_dsh"]),
+                _ptr(g["dL_dscales"]), _ptr(g["dL_drotations"]), int(bool(debug)), _stream(dev)))
+    return tuple(g[n] for n in shapes)
+
+
+class _AdamGroup(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("lr", ctypes.c_double), ("step", ctypes.c_int)]
+
+
+class _TrainState(ctypes.Structure):
+    """ngs_train_state of include/ngs_rasterizer.h."""
+    _fields_ = [("xyz", _AdamGroup), ("features", _AdamGroup), ("features_rest_lr", ctypes.c_double),
+                ("opacity", _AdamGroup), ("scaling", _AdamGroup), ("rotation", _AdamGroup),
+                ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
+                ("grad_scale", ctypes.c_float), ("xyz_gradient_accum", ctypes.c_void_p), ("denom", ctypes.c_void_p),
+                ("max_radii2D", ctypes.c_void_p)]
+
+
+def rasterize_gaussians_backward_train(background, radii, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                                       dL_dout_color, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                                       groups, features_rest_lr, betas=(0.9, 0.999), eps=1e-15, grad_scale=1.0,
+                                       densify=None, debug=False):
+    """Backward of ``rasterize_gaussians_raw`` with the optimiser step of every parameter group fused in: no
+    gradient is returned, the parameters take their Adam step in place.
+
+    ``groups`` maps "xyz", "features", "opacity", "scaling", "rotation" to (param, exp_avg, exp_avg_sq, lr, step):
+    float32 tensors [P,3], [P,16,3], [P,1], [P,3], [P,4] (opacity / scaling / rotation RAW), the learning rate and
+    the 1-based count of steps the group has taken including this one.  ``densify`` = (xyz_gradient_accum [P,1],
+    denom [P,1], max_radii2D [P] int32) also updates the densification statistics."""
+    xyz = groups["xyz"][0]
+    _require_gpu(xyz)
+    dev = xyz.device
+    P = xyz.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    st = _TrainState()
+    widths = dict(xyz=3, features=48, opacity=1, scaling=3, rotation=4)
+    for name, w in widths.items():
+        param, m, v, lr, step = groups[name]
+        for t in (param, m, v):
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != P * w:
+                raise RuntimeError("group %r: parameter and Adam moments must be contiguous float32 with %d elements "
+                                   "per Gaussian on %s" % (name, w, dev))
+        setattr(st, name, _AdamGroup(param.data_ptr(), m.data_ptr(), v.data_ptr(), float(lr), int(step)))
+    st.features_rest_lr = float(features_rest_lr)
+    st.beta1, st.beta2, st.eps, st.grad_scale = float(betas[0]), float(betas[1]), float(eps), float(grad_scale)
+    if densify is not None:
+        accum, denom, max_radii = densify
+        if (accum.dtype != torch.float32 or denom.dtype != torch.float32 or max_radii.dtype != torch.int32 or
+                any(t.numel() != P or t.device != dev or not t.is_contiguous() for t in densify)):
+            raise RuntimeError("densification statistics: float32 [P,1] x2 and int32 [P] on %s" % dev)
+        st.xyz_gradient_accum, st.denom, st.max_radii2D = accum.data_ptr(), denom.data_ptr(), max_radii.data_ptr()
+    background, viewmatrix, projmatrix, campos, dL_dout_color = (
+        _f32(x, dev) for x in (background, viewmatrix, projmatrix, campos, dL_dout_color))
+    if P != 0:
+        with torch.cuda.device(dev):
+            _check(lib().ngs_rasterize_backward_train(
+                P, int(degree), int(R), _ptr(background), W, H, ctypes.c_float(scale_modifier), _ptr(viewmatrix),
+                _ptr(projmatrix), _ptr(campos), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy),
+                _ptr(radii.contiguous()), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                _ptr(dL_dout_color), ctypes.byref(st), int(bool(debug)), _stream(dev)))
+
+
+def activate_parameters(opacity_raw, scales_raw, rotations_raw):
+    """-> (sigmoid(opacity_raw), exp(scales_raw), rotations_raw / max(|rotations_raw|, 1e-12)), computed with the
+    very expressions the raw-parameter kernels use (scene/gaussian_model.py:36-43)."""
+    _require_gpu(opacity_raw)
+    dev = opacity_raw.device
+    P = opacity_raw.numel()
+    opacity_raw, scales_raw, rotations_raw = (_f32(x, dev) for x in (opacity_raw, scales_raw, rotations_raw))
+    if scales_raw.numel() != 3 * P or rotations_raw.numel() != 4 * P:
+        raise RuntimeError("raw parameters must be [P,1], [P,3], [P,4]")
+    outs = tuple(torch.empty_like(t) for t in (opacity_raw, scales_raw, rotations_raw))
+    if P != 0:
+        with torch.cuda.device(dev):
+            _check(lib().ngs_activate_parameters(P, _ptr(opacity_raw), _ptr(scales_raw), _ptr(rotations_raw),
+                                                 _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _stream(dev)))
+    return outs
 
 
 def masked_color_gradient(geomBuffer, dL_dcolors, out=None):

@@ -13,7 +13,12 @@ What differs from the reference's way of running the same arithmetic:
   and their autograd graph;
 * the activations (sigmoid / exp / normalise, gaussian_model.py:36-43), their backward and Adam are one pass
   (``_C.adam_step`` / ``_C.adam_step_activated``): no autograd graph exists at all, the rasterizer's C ABI is called
-  directly and its gradients wrt the activated values feed the optimiser kernels.
+  directly and its gradients wrt the activated values feed the optimiser kernels;
+* on one GPU (``fused=True``, the default there) even those optimiser kernels disappear: the rasterizer reads the
+  RAW parameters (``_C.rasterize_gaussians_raw``) and its per-Gaussian backward kernel applies the activations'
+  backward and Adam to all five parameter groups while the gradients are still in registers
+  (``_C.rasterize_gaussians_backward_train``); no gradient and no activated copy is written to memory.  Both ways
+  produce bit-identical parameters.
 """
 import math
 
@@ -70,7 +75,7 @@ class GaussianTrainer:
     _ROWS = ("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw")
 
     def __init__(self, scene, device, opt=None, spatial_lr_scale=1.0, factored_exchange=True,
-                 densify_stats=True):
+                 densify_stats=True, fused=True):
         self.opt = opt or OptimizationParams()
         self.spatial_lr_scale = spatial_lr_scale
         dev = torch.device(device)
@@ -82,10 +87,9 @@ class GaussianTrainer:
         self.opacity_raw = inverse_sigmoid(f(scene.opacities))
         self.scaling_raw = torch.log(f(scene.scales))
         self.rotation_raw = f(scene.rotations)
-        # activated copies, kept in step with the raw values by the optimiser kernel
-        self.opacities = torch.sigmoid(self.opacity_raw)
-        self.scales = torch.exp(self.scaling_raw)
-        self.rotations = torch.nn.functional.normalize(self.rotation_raw)
+        # activated copies: kept in step with the raw values by the optimiser kernel, or (fused steps, which never
+        # read them) recomputed when somebody asks
+        self._activate()
         self.state = {}
         for name in ("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw"):
             p = getattr(self, name)
@@ -101,6 +105,8 @@ class GaussianTrainer:
         self.world = world
         self.factored_exchange = factored_exchange
         self.densify_stats = densify_stats
+        # one GPU, full SH rows: the whole optimiser step runs inside the backward pass
+        self.fused = bool(fused) and world == 1 and self.M == 16 and dev.type == "cuda"
         self._workspace = None
         self._dL_dpix = None
         self._resized()
@@ -189,9 +195,25 @@ class GaussianTrainer:
             self.max_radii2D = torch.zeros(self.P, dtype=torch.int32, device=dev)
 
     def _activate(self):
-        self.opacities = torch.sigmoid(self.opacity_raw)
-        self.scales = torch.exp(self.scaling_raw)
-        self.rotations = torch.nn.functional.normalize(self.rotation_raw)
+        """Activated copies of the raw parameters (gaussian_model.py:36-43).  On the GPU they come from the library,
+        whose raw-parameter kernels apply the very same expressions."""
+        if self.opacity_raw.is_cuda:
+            self._opacities, self._scales, self._rotations = _C.activate_parameters(
+                self.opacity_raw, self.scaling_raw, self.rotation_raw)
+        else:
+            self._opacities = torch.sigmoid(self.opacity_raw)
+            self._scales = torch.exp(self.scaling_raw)
+            self._rotations = torch.nn.functional.normalize(self.rotation_raw)
+        self._stale = False
+
+    def _activated(self, name):
+        if self._stale:
+            self._activate()
+        return getattr(self, name)
+
+    opacities = property(lambda self: self._activated("_opacities"))
+    scales = property(lambda self: self._activated("_scales"))
+    rotations = property(lambda self: self._activated("_rotations"))
 
     def oneupSHdegree(self):  # gaussian_model.py:146-148
         if self.sh_degree < self.max_sh_degree:
@@ -231,6 +253,8 @@ class GaussianTrainer:
                                                 out=self._dL_dpix)
             return dL
 
+        if self.fused and optimize:
+            return self._fused_step(cam, gt_image, bg, tanfovx, tanfovy, loss_grad, terms, hold_opacity, stats)
         scene = self.scene_view()
         # On one rank the SH coefficients (four fifths of all parameters) are stepped inside the backward pass: their
         # gradient is consumed where it is produced instead of travelling through memory to a separate Adam kernel.
@@ -272,9 +296,37 @@ class GaussianTrainer:
             tuple(getattr(self, n) for n in names),
             (g["dL_dopacity"], g["dL_dscales"], g["dL_drotations"]),
             tuple(self.state[n][0] for n in names), tuple(self.state[n][1] for n in names),
-            (self.opacities, self.scales, self.rotations),
+            (self._opacities, self._scales, self._rotations),
             (0.0 if hold_opacity else o.opacity_lr, o.scaling_lr, o.rotation_lr),
             tuple(max(steps[n], 1) for n in names), grad_scale=scale, densify=densify)
+        return terms["loss"], color, radii
+
+    def _fused_step(self, cam, gt_image, bg, tanfovx, tanfovy, loss_grad, terms, hold_opacity, stats):
+        """The iteration with the optimiser inside the backward pass: raw parameters in, updated raw parameters
+        out, nothing in between reaches memory but the image and its gradient."""
+        o, steps = self.opt, self.adam_steps
+        for name in steps:
+            if not (hold_opacity and name == "opacity_raw"):
+                steps[name] += 1
+        e = torch.empty(0)
+        H, W = int(cam.image_height), int(cam.image_width)
+        R, color, radii, geom, binning, img = _C.rasterize_gaussians_raw(
+            bg, self.xyz, e, self.opacity_raw, self.scaling_raw, self.rotation_raw, 1.0, cam.world_view_transform,
+            cam.full_proj_transform, tanfovx, tanfovy, H, W, self.features, self.sh_degree, cam.camera_center, False,
+            False)
+        dL_dpix = loss_grad(color)
+        lrs = dict(xyz=self.xyz_lr(self.iteration), features=o.feature_lr,
+                   opacity_raw=0.0 if hold_opacity else o.opacity_lr, scaling_raw=o.scaling_lr,
+                   rotation_raw=o.rotation_lr)
+        names = dict(xyz="xyz", features="features", opacity="opacity_raw", scaling="scaling_raw",
+                     rotation="rotation_raw")
+        groups = {k: (getattr(self, n),) + self.state[n] + (lrs[n], max(steps[n], 1)) for k, n in names.items()}
+        densify = (self.xyz_gradient_accum, self.denom, self.max_radii2D) if stats else None
+        _C.rasterize_gaussians_backward_train(
+            bg, radii, 1.0, cam.world_view_transform, cam.full_proj_transform, tanfovx, tanfovy, dL_dpix,
+            self.sh_degree, cam.camera_center, geom, R, binning, img, groups, o.feature_lr / 20.0,
+            grad_scale=1.0 / self.world, densify=densify)
+        self._stale = True
         return terms["loss"], color, radii
 
     # ---- everything below changes the set of Gaussians: host-side tensor surgery as in the reference ----
@@ -361,7 +413,7 @@ class GaussianTrainer:
         cap = torch.full_like(self.opacity_raw, 0.01)
         self.opacity_raw = inverse_sigmoid(torch.min(torch.sigmoid(self.opacity_raw), cap)).contiguous()
         self.state["opacity_raw"] = (torch.zeros_like(self.opacity_raw), torch.zeros_like(self.opacity_raw))
-        self.opacities = torch.sigmoid(self.opacity_raw)
+        self._activate()
 
     def train_iteration(self, cam, gt_image, bg, tanfovx, tanfovy, scene_extent, white_background=False, seed=0):
         """The whole loop body of train.py:69-128 for iteration ``self.iteration + 1``.

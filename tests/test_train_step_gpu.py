@@ -696,3 +696,158 @@ def test_activated_adam_aligned_and_unaligned_paths_agree(C):
             results.append([t.clone() for t in groups[0] + groups[2] + groups[3] + act])
         for a, b in zip(*results):
             assert torch.equal(a, b), P
+
+
+def _raw_scene(config, seed=5):
+    if config in ("c2", "c3"):
+        sc, W, H = synthetic.make_config(config)
+        shs = sc.shs
+        if shs.shape[1] != 16:  # the raw entry points take any coefficient count; the fused step wants full rows
+            shs = torch.cat([shs, torch.zeros(shs.shape[0], 16 - shs.shape[1], 3)], dim=1)
+        sc = synthetic.Scene(sc.means3D, shs.contiguous(), sc.opacities, sc.scales, sc.rotations, sc.sh_degree)
+    else:
+        P, W, H = 5000, 200, 120
+        sc = synthetic.make_scene(P, 3, (-4.0, -2.8), (1.3, 1.3, 1.3), seed=seed, sh_coeffs=16)
+    g = torch.Generator().manual_seed(seed)
+    raw = dict(opacity=train_step.inverse_sigmoid(sc.opacities), scaling=torch.log(sc.scales),
+               rotation=sc.rotations * (0.5 + torch.rand(sc.rotations.shape[0], 1, generator=g) * 2.0))  # not unit length
+    return sc.to(DEV), {k: v.to(DEV).contiguous() for k, v in raw.items()}, W, H
+
+
+@pytest.mark.parametrize("config", ["small", "c2", "c3"])
+def test_raw_parameter_path_equals_activated_path(C, config):
+    """rasterize_gaussians_raw on (inverse-sigmoid opacity, log scale, unnormalised quaternion) against
+    rasterize_gaussians on the activated values: image, radii and instance count bit-equal; the raw gradients equal
+    the activated ones pushed through the activations' backward in float32, operation by operation."""
+    sc, raw, W, H = _raw_scene(config)
+    P, D = sc.means3D.shape[0], sc.sh_degree
+    cam = make_camera(W, H, synthetic.FOVX, (0.7, 0.5, -4.0), device=DEV)
+    tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    bg, e = torch.tensor([0.1, 0.2, 0.3], device=DEV), torch.empty(0)
+    op, scl, rot = C.activate_parameters(raw["opacity"], raw["scaling"], raw["rotation"])
+    assert torch.allclose(op, torch.sigmoid(raw["opacity"]), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(scl, torch.exp(raw["scaling"]), rtol=1e-6)
+    assert torch.allclose(rot, torch.nn.functional.normalize(raw["rotation"]), rtol=1e-6, atol=1e-7)
+    view = (cam.world_view_transform, cam.full_proj_transform, tanx, tany)
+    a = C.rasterize_gaussians(bg, sc.means3D, e, op, scl, rot, 1.0, e, *view, H, W, sc.shs, D, cam.camera_center,
+                              False, False)
+    r = C.rasterize_gaussians_raw(bg, sc.means3D, e, raw["opacity"], raw["scaling"], raw["rotation"], 1.0, *view, H, W,
+                                  sc.shs, D, cam.camera_center, False, False)
+    assert a[0] == r[0] and a[0] > 0
+    assert torch.equal(a[1], r[1]) and torch.equal(a[2], r[2])
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(9)).to(DEV)
+    ga = C.rasterize_gaussians_backward(bg, sc.means3D, a[2], e, scl, rot, 1.0, e, *view, dL, sc.shs, D,
+                                        cam.camera_center, a[3], a[0], a[4], a[5], False)
+    gr = C.rasterize_gaussians_backward_raw(bg, sc.means3D, r[2], e, raw["opacity"], raw["scaling"], raw["rotation"],
+                                            1.0, *view, dL, sc.shs, D, cam.camera_center, r[3], r[0], r[4], r[5], False)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations")
+    ga, gr = dict(zip(names, ga)), dict(zip(names, gr))
+    # float atomics land in a different order in the two compositing passes: gradients agree to rounding, not bits
+    def close(x, y, what):
+        big = float(y.abs().max())
+        assert float((x - y).abs().max()) <= 2e-5 * big + 1e-12, what
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh"):
+        close(gr[k], ga[k], k)
+    close(gr["dL_dopacity"], ga["dL_dopacity"] * ((1.0 - op) * op), "opacity")
+    close(gr["dL_dscales"], ga["dL_dscales"] * scl, "scales")
+    g = ga["dL_drotations"]
+    t = rot * g
+    dot = ((t[:, 0] + t[:, 1]) + t[:, 2]) + t[:, 3]
+    s = raw["rotation"] * raw["rotation"]
+    length = torch.sqrt(((s[:, 0] + s[:, 1]) + s[:, 2]) + s[:, 3]).clamp_min(1e-12)
+    close(gr["dL_drotations"], (g - rot * dot[:, None]) / length[:, None], "rotations")
+    # against autograd through torch's own activations (what the reference differentiates)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+    acts = (torch.sigmoid(leaf["opacity"]), torch.exp(leaf["scaling"]), torch.nn.functional.normalize(leaf["rotation"]))
+    torch.autograd.backward(acts, (ga["dL_dopacity"], ga["dL_dscales"], ga["dL_drotations"]))
+    for k, name in (("opacity", "dL_dopacity"), ("scaling", "dL_dscales"), ("rotation", "dL_drotations")):
+        big = float(leaf[k].grad.abs().max())
+        assert float((gr[name] - leaf[k].grad).abs().max()) <= 1e-4 * big, k
+    # culled Gaussians get exact zeros
+    culled = r[2] == 0
+    assert int(culled.sum()) > 0 or config == "small"
+    for k in names:
+        assert float(gr[k][culled].abs().sum()) == 0.0, k
+
+
+@pytest.mark.parametrize("config", ["small", "c3"])
+def test_fused_training_equals_separate_optimiser_kernels(C, config):
+    """The optimiser step inside the backward pass (raw parameters in and out, no gradient in memory) against the
+    same iterations with gradients written out and separate Adam kernels reading activated copies: parameters,
+    moments and densification statistics stay BIT-identical only if both see the same gradients, and the float
+    atomics of two compositing passes need not agree in order -- so the comparison is at rounding level on the
+    first step and, where Adam's sign-like first steps amplify a rounding-level gradient, within a few learning
+    rates for a handful of elements afterwards."""
+    if config == "c3":
+        sc, W, H = synthetic.make_config("c3")
+    else:
+        W, H = 200, 120
+        sc = synthetic.make_scene(6000, 3, (-4.0, -2.8), (1.3, 1.3, 1.3), seed=8, sh_coeffs=16)
+    cams = [make_camera(W, H, synthetic.FOVX, e, device=DEV) for e in ((0.7, 0.5, -4.0), (-2.0, 0.4, -3.4), (1.5, -0.3, -3.6))]
+    gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(70 + i)).to(DEV) for i in range(3)]
+    bg = torch.zeros(3, device=DEV)
+    a = train_step.GaussianTrainer(sc, DEV, fused=True)
+    b = train_step.GaussianTrainer(sc, DEV, fused=False)
+    assert a.fused and not b.fused
+    rows = ("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw")
+    lr_of = dict(xyz=a.opt.position_lr_init, features=a.opt.feature_lr, opacity_raw=a.opt.opacity_lr,
+                 scaling_raw=a.opt.scaling_lr, rotation_raw=a.opt.rotation_lr)
+    for it in range(4):
+        cam, gt = cams[it % 3], gts[it % 3]
+        tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        hold = it == 2  # an opacity-reset iteration: the opacities keep their values, their moments still move
+        ta, ca, ra = a.step(cam, gt, bg, tanx, tany, hold_opacity=hold)
+        tb, cb, rb = b.step(cam, gt, bg, tanx, tany, hold_opacity=hold)
+        if it == 0:
+            assert torch.equal(ca, cb) and torch.equal(ra, rb) and torch.equal(ta, tb)  # same parameters, same image
+        for n in rows:
+            pa, pb = getattr(a, n), getattr(b, n)
+            diff = (pa - pb).abs()
+            assert float((diff <= 1e-3 * lr_of[n]).float().mean()) > 0.995, (it, n)
+            assert float(diff.max()) <= 6.5 * lr_of[n], (it, n)
+            for ma, mb in zip(a.state[n], b.state[n]):
+                big = float(mb.abs().max())
+                assert float((ma - mb).abs().max()) <= 1e-3 * big + 1e-20, (it, n)
+        if hold:
+            assert a.adam_steps == b.adam_steps and a.adam_steps["opacity_raw"] == it
+    assert torch.equal(a.denom, b.denom) and torch.equal(a.max_radii2D, b.max_radii2D)
+    assert torch.allclose(a.xyz_gradient_accum, b.xyz_gradient_accum, rtol=1e-3, atol=1e-9)
+    # the activated copies follow on demand
+    op, scl, rot = C.activate_parameters(a.opacity_raw, a.scaling_raw, a.rotation_raw)
+    assert torch.equal(a.opacities, op) and torch.equal(a.scales, scl) and torch.equal(a.rotations, rot)
+
+
+def test_fused_optimiser_step_is_bit_exact_given_the_same_gradients(C):
+    """A scene whose compositing sums have ONE order only: every Gaussian is a speck whose visible pixels (alpha >=
+    1/255) lie inside a single 4x4 pixel quadrant, so each of its gradient sums is reduced inside one 16-lane row
+    and reaches memory as a single atomic.  Both ways of stepping then see bit-identical gradients, and because the
+    optimiser arithmetic is shared code, parameters, moments and statistics must stay bit-identical throughout."""
+    W, H, D = 256, 192, 3
+    P = (W // 32) * (H // 32)
+    g = torch.Generator().manual_seed(3)
+    cam = make_camera(W, H, synthetic.FOVX, (0.0, 0.0, -4.0), device=DEV)
+    tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    gx, gy = torch.meshgrid(torch.arange(W // 32), torch.arange(H // 32), indexing="ij")
+    # pixel (32 i + 17, 32 j + 17): second pixel of a quadrant whichever way the camera's axes point
+    px, py = 32.0 * gx.reshape(-1) + 17.0, 32.0 * gy.reshape(-1) + 17.0
+    means = torch.stack([((2 * px + 1) / W - 1) * tanx * 4.0, ((2 * py + 1) / H - 1) * tany * 4.0, torch.zeros(P)], dim=1)
+    sc = synthetic.Scene(means, torch.randn(P, 16, 3, generator=g) * 0.3, torch.full((P, 1), 0.5),
+                         0.002 * (1 + 0.2 * torch.rand(P, 3, generator=g)),
+                         torch.nn.functional.normalize(torch.randn(P, 4, generator=g)), D)
+    a = train_step.GaussianTrainer(sc, DEV, fused=True)
+    b = train_step.GaussianTrainer(sc, DEV, fused=False)
+    gt = torch.rand(3, H, W, generator=g).to(DEV)
+    bg = torch.zeros(3, device=DEV)
+    rows = ("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw")
+    for it in range(4):
+        ta, ca, ra = a.step(cam, gt, bg, tanx, tany, hold_opacity=it == 2)
+        tb, cb, rb = b.step(cam, gt, bg, tanx, tany, hold_opacity=it == 2)
+        assert int((ra > 0).sum()) == P and int(ra.max()) <= 3
+        assert torch.equal(ca, cb) and torch.equal(ta, tb), it
+        for n in rows:
+            assert torch.equal(getattr(a, n), getattr(b, n)), (it, n)
+            assert torch.equal(a.state[n][0], b.state[n][0]) and torch.equal(a.state[n][1], b.state[n][1]), (it, n)
+    assert not torch.equal(a.xyz, sc.means3D.to(DEV))
+    assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and float(a.xyz_gradient_accum.sum()) > 0
+    assert torch.equal(a.denom, b.denom) and torch.equal(a.max_radii2D, b.max_radii2D)
