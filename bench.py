@@ -109,6 +109,10 @@ def main():
     ap.add_argument("--exchange", default="factored", choices=("factored", "dense"),
                     help="gradient exchange at N > 1: all-gather of masked colour gradients + all-reduce of the other "
                          "11 floats per Gaussian (default), or one dense all-reduce of all 59")
+    ap.add_argument("--views-per-gpu", type=int, default=1,
+                    help="views each GPU renders per step (the step's gradient is the sum over all GPUs' views): with "
+                         "more than one, a view's collectives travel while the next view is rendered and only the "
+                         "last view's exchange is exposed; a step then covers that many images per GPU")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo lets several ranks share one GPU to rehearse the N > 1 path on a one-GPU box")
     ap.add_argument("--unfused-train", action="store_true",
@@ -152,21 +156,25 @@ def main():
     ls = (ls[0] + args.log_scale_offset, ls[1] + args.log_scale_offset)
     scene_cpu = synthetic.make_scene(P, D, ls, ext, 1234, M)  # same seed everywhere: replicated parameters
     scene = scene_cpu.to(dev)
-    cam = synthetic.make_view(W, H, index=rank, count=8, device=dev)  # one orbit view per rank
+    V = max(args.views_per_gpu, 1)
+    # orbit views: rank r renders views r*V .. r*V+V-1 of the orbit (view 0 of rank 0 is the single-GPU workload)
+    cams = [synthetic.make_view(W, H, index=rank * V + k, count=8 * V if V > 1 else 8, device=dev) for k in range(V)]
+    cam = cams[0]
     tanx, tany = synthetic.tan_half_fov(cam)
     bg = torch.zeros(3, device=dev)
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     dL = (torch.randn(3, H, W, generator=gen) / float(W * H)).to(dev)
-    if world > 1 and args.exchange == "factored":
-        bucket = view_parallel.FactoredGradientExchange(P, M, dev)
-        exchanged_floats = bucket.row + bucket.reduced.numel()
+    if (world > 1 or V > 1) and args.exchange == "factored":
+        bucket = view_parallel.FactoredGradientExchange(P, M, dev, views_per_rank=V)
     else:
-        bucket = view_parallel.GradientBucket(P, M, dev)
-        exchanged_floats = bucket.flat.numel()
+        bucket = view_parallel.GradientBucket(P, M, dev, views_per_rank=V)
+    exchanged_floats = bucket.bytes_sent_per_rank() // 4
 
     def step():
-        out = view_parallel.forward_backward(scene, cam, bg, lambda color: dL, bucket, tanx, tany)
-        bucket.reduce(scene, cam, out[2])
+        for k in range(V):
+            out = view_parallel.forward_backward(scene, cams[k], bg, lambda color: dL, bucket, tanx, tany, slot=k)
+            bucket.post_view(k, scene, cams[k], out[2])
+        bucket.finish(scene)
         return out
 
     def fence():
@@ -235,17 +243,18 @@ def main():
     if train_steps > 0:
         from neuralgaussiansplatting_amd import train_step
         trainer = train_step.GaussianTrainer(scene, dev, factored_exchange=args.exchange == "factored",
-                                             fused=not args.unfused_train)
+                                             fused=not args.unfused_train, views_per_rank=V)
         gt = torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(4321 + rank)).to(dev)
+        train_args = (cams, [gt] * V) if V > 1 else (cam, gt)
         for _ in range(train_warmup):
-            trainer.step(cam, gt, bg, tanx, tany)
+            trainer.step(*train_args, bg, tanx, tany)
         _C.profile_enable(not args.no_stage_timing)
         _C.profile_read(reset=True)
         with quiet_host():
             fence()
             t0 = time.perf_counter()
             for _ in range(train_steps):
-                trainer.step(cam, gt, bg, tanx, tany)
+                trainer.step(*train_args, bg, tanx, tany)
             fence()
             t_train = time.perf_counter() - t0
         train_stages = _C.profile_read(reset=True)
@@ -322,7 +331,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * W * H * args.steps / elapsed / 1e6
+        value = world * V * W * H * args.steps / elapsed / 1e6
         # statistics that need the state buffers: one extra untimed forward
         e = torch.empty(0)
         Rr, _, radii2, geom, binning, img = _C.rasterize_gaussians(
@@ -387,7 +396,8 @@ def main():
                             "adam_identity_groups": "adam_positions_only"}.get(name, name) if fused else name
                     per_iter[name] = {"ms_per_iter": round(ms, 4), "launches_per_iter": round(cnt / train_steps, 2),
                                       "GB_per_s": round(nbytes[bkey] / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
-            train_out = {"iters_per_s": round(world * train_steps / t_train, 2),
+            train_out = {"iters_per_s": round(train_steps / t_train, 2),
+                         "views_per_s": round(world * V * train_steps / t_train, 2),
                          "ms_per_iter": round(t_train / train_steps * 1e3, 4), "steps": train_steps,
                          "what": ("lr schedule + render from the raw parameters + fused L1/D-SSIM loss + backward with "
                                   "the activations' backward, Adam of all five parameter groups and the "
@@ -404,14 +414,16 @@ def main():
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "iters_per_s": round(world * args.steps / elapsed, 2),
-            "config": {"workload": "%s%s: %d Gaussians, %dx%d, SH degree %d (M=%d), one orbit view per GPU, "
+            "iters_per_s": round(world * V * args.steps / elapsed, 2),
+            "config": {"workload": "%s%s: %d Gaussians, %dx%d, SH degree %d (M=%d), %s per GPU and step, "
                                    "fwd+bwd%s" % (args.config,
                                                   "" if args.log_scale_offset == 0.0 else
                                                   " with log-scale offset %+.2f" % args.log_scale_offset,
                                                   P, W, H, D, M,
-                                                  " + %s gradient exchange of %d floats per rank"
+                                                  "one orbit view" if V == 1 else "%d orbit views" % V,
+                                                  " + %s gradient exchange of %d floats per rank and step"
                                                   % (args.exchange, exchanged_floats) if world > 1 else ""),
+                       "views_per_gpu": V,
                        "gaussians": P, "width": W, "height": H, "sh_degree": D, "instances_R": int(R),
                        "instances_per_gaussian": round(R / P, 2), "log_scale": [round(v, 3) for v in ls],
                        "kernel_sources_sha": build_id.kernel_sources_sha(),

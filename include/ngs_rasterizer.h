@@ -255,7 +255,14 @@ size_t ngs_required_image_bytes(int width, int height);
  * ngs_sh_adam_from_views: as ngs_sh_gradient_from_views, but the summed gradient is not written: the Adam step of
  * the SH coefficients is applied to `shs` ([P][16][3], in place) and its moments directly (arguments as in
  * ngs_rasterize_backward_sh_adam; grad_scale = 1/V turns the sum into the mean over the views).
+ *
+ * ngs_view_statistics: one view's densification statistics in summable form, so that they can ride in the same
+ * all-reduce as the gradients: norm_out[i] = |dL_dmean2D[i].xy| and vis_out[i] = 1 where radii[i] > 0, zeros
+ * elsewhere (the increments of xyz_gradient_accum and denom, scene/gaussian_model.py:550-552); max_radii2D (may be
+ * NULL) takes the running maximum of radii in place (train.py:115), which ranks merge with an integer max.
  */
+int ngs_view_statistics(int P, const float* dL_dmean2D, const int* radii, float* norm_out, float* vis_out,
+                        int* max_radii2D, void* stream);
 int ngs_masked_color_gradient(int P, const char* geom_buffer, const float* dL_dcolor, float* out, void* stream);
 int ngs_sh_adam_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
                            long long campos_stride, const float* dL_dcolor_views, long long view_stride, float* shs,

@@ -824,6 +824,19 @@ extern "C" int ngs_adam_step_activated(int P, float* const raw[3], const float* 
     return 0;
 }
 
+extern "C" int ngs_view_statistics(int P, const float* dL_dmean2D, const int* radii, float* norm_out, float* vis_out,
+                                   int* max_radii2D, void* stream)
+{
+    g_err[0] = 0;
+    if (P < 0) return fail("ngs_view_statistics", "bad size");
+    if (P == 0) return 0;
+    if (!dL_dmean2D || !radii || !norm_out || !vis_out) return fail("ngs_view_statistics", "missing required pointer");
+    ngs_launch_view_statistics((hipStream_t)stream, P, dL_dmean2D, radii, norm_out, vis_out, max_radii2D);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("stage view statistics", hipGetErrorString(e));
+    return 0;
+}
+
 extern "C" int ngs_activate_parameters(int P, const float* opacities_raw, const float* scales_raw,
                                        const float* rotations_raw, float* opacities, float* scales, float* rotations,
                                        void* stream)

@@ -285,6 +285,8 @@ void ngs_launch_adam_activated(hipStream_t s, int P, float* const raw[3], const 
                                const double lr[3], double beta1, double beta2, double eps, const int step[3],
                                float grad_scale, const float* dL_dmean2D, const int* radii, float* grad_accum,
                                float* denom, int* max_radii);
+void ngs_launch_view_statistics(hipStream_t s, int P, const float* dL_dmean2D, const int* radii, float* norm_out,
+                                float* vis_out, int* max_radii);
 void ngs_launch_activate(hipStream_t s, int P, const float* op_raw, const float* sc_raw, const float* ro_raw,
                          float* op, float* sc, float* ro);
 

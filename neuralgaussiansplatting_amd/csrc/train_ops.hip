@@ -494,6 +494,28 @@ __global__ __launch_bounds__(256) void adam_activated_vec_kernel(int P, Activate
     }
 }
 
+// One view's densification statistics as two summable rows (scene/gaussian_model.py:550-552): the view-space gradient
+// norm and the visibility flag of every Gaussian, zeros where it was not rendered; the running maximum of the screen
+// radius (train.py:115) is updated in place when given.  Ranks sum the rows together with their gradients.
+__global__ __launch_bounds__(256) void view_statistics_kernel(int P, const float* __restrict__ dL_dmean2D,
+                                                              const int* __restrict__ radii,
+                                                              float* __restrict__ norm_out, float* __restrict__ vis_out,
+                                                              int* __restrict__ max_radii)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    float n = 0.0f, v = 0.0f;
+    if (r > 0) {
+        const float gx = dL_dmean2D[3 * (size_t)i], gy = dL_dmean2D[3 * (size_t)i + 1];
+        n = sqrtf(gx * gx + gy * gy);
+        v = 1.0f;
+        if (max_radii) max_radii[i] = max(max_radii[i], r);
+    }
+    norm_out[i] = n;
+    vis_out[i] = v;
+}
+
 // The three activations on their own (any output may be NULL); element accesses, no alignment needed.
 __global__ __launch_bounds__(256) void activate_kernel(int P, const float* __restrict__ op_raw,
                                                        const float* __restrict__ sc_raw,
@@ -602,4 +624,11 @@ void ngs_launch_activate(hipStream_t s, int P, const float* op_raw, const float*
                          float* op, float* sc, float* ro)
 {
     hipLaunchKernelGGL(activate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, op_raw, sc_raw, ro_raw, op, sc, ro);
+}
+
+void ngs_launch_view_statistics(hipStream_t s, int P, const float* dL_dmean2D, const int* radii, float* norm_out,
+                                float* vis_out, int* max_radii)
+{
+    hipLaunchKernelGGL(view_statistics_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, dL_dmean2D, radii, norm_out,
+                       vis_out, max_radii);
 }

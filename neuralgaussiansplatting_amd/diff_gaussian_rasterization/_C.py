@@ -40,6 +40,7 @@ def lib():
         L.ngs_rasterize_backward_raw.restype = ctypes.c_int
         L.ngs_rasterize_backward_train.restype = ctypes.c_int
         L.ngs_activate_parameters.restype = ctypes.c_int
+        L.ngs_view_statistics.restype = ctypes.c_int
         L.ngs_mark_visible.restype = ctypes.c_int
         L.ngs_state_layout.restype = ctypes.c_int
         L.ngs_masked_color_gradient.restype = ctypes.c_int
@@ -408,6 +409,26 @@ def masked_color_gradient(geomBuffer, dL_dcolors, out=None):
         with torch.cuda.device(dev):
             _check(lib().ngs_masked_color_gradient(P, _ptr(geomBuffer), _ptr(dL_dcolors), _ptr(out), _stream(dev)))
     return out.view(P, 3)
+
+
+def view_statistics(dL_dmeans2D, radii, norm_out, vis_out, max_radii2D=None):
+    """One view's densification statistics as two summable float rows of P elements (see ngs_view_statistics in
+    include/ngs_rasterizer.h); ``max_radii2D`` (int32 [P]) takes the running maximum of ``radii`` in place."""
+    _require_gpu(dL_dmeans2D)
+    dev = dL_dmeans2D.device
+    P = radii.numel()
+    dL_dmeans2D = _f32(dL_dmeans2D, dev)
+    for t in (norm_out, vis_out):
+        if t.numel() != P or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+            raise RuntimeError("statistics rows must be contiguous float32 tensors with %d elements on %s" % (P, dev))
+    if radii.dtype != torch.int32 or dL_dmeans2D.numel() != 3 * P or (
+            max_radii2D is not None and (max_radii2D.dtype != torch.int32 or max_radii2D.numel() != P or
+                                         not max_radii2D.is_contiguous())):
+        raise RuntimeError("view statistics: dL_dmeans2D float32 [P,3], radii / max_radii2D int32 [P]")
+    if P != 0:
+        with torch.cuda.device(dev):
+            _check(lib().ngs_view_statistics(P, _ptr(dL_dmeans2D), _ptr(radii.contiguous()), _ptr(norm_out),
+                                             _ptr(vis_out), _ptr(max_radii2D), _stream(dev)))
 
 
 def sh_gradient_from_views(means3D, campos, dL_dcolor_views, degree, M, out=None, sh_adam=None):

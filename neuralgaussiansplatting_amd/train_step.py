@@ -68,14 +68,16 @@ def inverse_sigmoid(x):
 class GaussianTrainer:
     """Raw parameters, Adam state and the activated copies the rasterizer reads, all resident on one GPU.
 
-    With a process group, every rank steps its own view and the gradients are averaged over the ranks' views before
-    Adam, so all ranks hold identical parameters.  The densification statistics are this rank's views only:
-    ``sync_densification_stats()`` merges them over the ranks before densifying."""
+    With a process group, every rank steps its own ``views_per_rank`` views and the gradients are averaged over all
+    ranks' views before Adam, so all ranks hold identical parameters; a view's collectives travel while the next
+    view is rendered.  The sums of the densification statistics ride in the same collectives (every rank holds
+    their totals after every step); the largest screen radius is this rank's views only until
+    ``sync_densification_stats()`` merges it before densifying."""
 
     _ROWS = ("xyz", "features", "opacity_raw", "scaling_raw", "rotation_raw")
 
     def __init__(self, scene, device, opt=None, spatial_lr_scale=1.0, factored_exchange=True,
-                 densify_stats=True, fused=True):
+                 densify_stats=True, fused=True, views_per_rank=1):
         self.opt = opt or OptimizationParams()
         self.spatial_lr_scale = spatial_lr_scale
         dev = torch.device(device)
@@ -103,10 +105,11 @@ class GaussianTrainer:
         world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
                                                        torch.distributed.is_initialized()) else 1
         self.world = world
+        self.views_per_rank = int(views_per_rank)
         self.factored_exchange = factored_exchange
         self.densify_stats = densify_stats
         # one GPU, full SH rows: the whole optimiser step runs inside the backward pass
-        self.fused = bool(fused) and world == 1 and self.M == 16 and dev.type == "cuda"
+        self.fused = bool(fused) and world == 1 and self.views_per_rank == 1 and self.M == 16 and dev.type == "cuda"
         self._workspace = None
         self._dL_dpix = None
         self._resized()
@@ -186,9 +189,12 @@ class GaussianTrainer:
         """(Re)build everything whose size follows the number of Gaussians: gradient buffers, statistics."""
         dev = self.xyz.device
         self.P = self.xyz.shape[0]
-        self.exchange = (view_parallel.FactoredGradientExchange(self.P, self.M, dev)
-                         if self.world > 1 and self.factored_exchange
-                         else view_parallel.GradientBucket(self.P, self.M, dev))
+        # several views per step (over ranks or on one rank): the statistics' sums travel with the gradients
+        self.batched = self.world > 1 or self.views_per_rank > 1
+        kw = dict(stats=self.densify_stats and self.batched, views_per_rank=self.views_per_rank)
+        self.exchange = (view_parallel.FactoredGradientExchange(self.P, self.M, dev, **kw)
+                         if self.batched and self.factored_exchange
+                         else view_parallel.GradientBucket(self.P, self.M, dev, **kw))
         if self.densify_stats:  # gaussian_model.py:486-488
             self.xyz_gradient_accum = torch.zeros((self.P, 1), device=dev)
             self.denom = torch.zeros((self.P, 1), device=dev)
@@ -220,9 +226,11 @@ class GaussianTrainer:
             self.sh_degree += 1
 
     def sync_densification_stats(self, group=None):
-        """Totals over all ranks' views, in place (see ``view_parallel.sync_densification_stats``)."""
+        """Totals over all ranks' views, in place (see ``view_parallel.sync_densification_stats``); the sums are
+        already global, they travelled with every step's gradients."""
         if self.densify_stats:
-            view_parallel.sync_densification_stats(self.xyz_gradient_accum, self.denom, self.max_radii2D, group)
+            view_parallel.sync_densification_stats(self.xyz_gradient_accum, self.denom, self.max_radii2D, group,
+                                                   sums=False)
 
     def scene_view(self):
         """The activated tensors in the shape ``view_parallel.forward_backward`` expects."""
@@ -236,9 +244,12 @@ class GaussianTrainer:
                         max_steps=o.position_lr_max_steps)
 
     def step(self, cam, gt_image, bg, tanfovx, tanfovy, optimize=True, hold_opacity=False, collect_stats=True):
-        """One iteration on this rank's view.  Returns (loss_terms, color, radii); loss_terms stays on the device.
-        ``optimize=False`` renders and differentiates (statistics are still gathered) but moves no parameter;
-        ``hold_opacity`` leaves the opacities alone while everything else takes its step."""
+        """One iteration on this rank's view -- or views: with ``views_per_rank`` > 1, ``cam`` and ``gt_image`` are
+        sequences of that length.  Returns (loss_terms, color, radii) of the (last) view; loss_terms stays on the
+        device.  ``optimize=False`` renders and differentiates (statistics are still gathered) but moves no
+        parameter; ``hold_opacity`` leaves the opacities alone while everything else takes its step."""
+        if self.batched:
+            return self._batched_step(cam, gt_image, bg, tanfovx, tanfovy, optimize, hold_opacity, collect_stats)
         self.iteration += 1
         it, o = self.iteration, self.opt
         stats = self.densify_stats and collect_stats
@@ -258,8 +269,6 @@ class GaussianTrainer:
         scene = self.scene_view()
         # On one rank the SH coefficients (four fifths of all parameters) are stepped inside the backward pass: their
         # gradient is consumed where it is produced instead of travelling through memory to a separate Adam kernel.
-        scale = 1.0 / self.world  # the batch loss is the mean over the views of all ranks
-        factored = isinstance(self.exchange, view_parallel.FactoredGradientExchange)
         if not optimize:
             color, radii, aux = view_parallel.forward_backward(scene, cam, bg, loss_grad, self.exchange, tanfovx,
                                                                tanfovy)
@@ -270,27 +279,31 @@ class GaussianTrainer:
         for name in steps:
             if not (hold_opacity and name == "opacity_raw"):
                 steps[name] += 1
-        fused_sh = self.M == 16 and (self.world == 1 or factored)
+        fused_sh = self.M == 16
         sh_adam = None
-        if fused_sh:
+        if fused_sh:  # inside the backward pass
             m, v = self.state["features"]
             sh_adam = dict(param=self.features, exp_avg=m, exp_avg_sq=v, lr_dc=o.feature_lr,
-                           lr_rest=o.feature_lr / 20.0, step=steps["features"], grad_scale=scale)
-        # one rank: inside the backward pass; several ranks: inside the kernel that rebuilds the all-view SH gradient
+                           lr_rest=o.feature_lr / 20.0, step=steps["features"], grad_scale=1.0)
         color, radii, aux = view_parallel.forward_backward(scene, cam, bg, loss_grad, self.exchange, tanfovx, tanfovy,
-                                                           sh_adam=sh_adam if self.world == 1 else None)
-        self.exchange.reduce(scene, cam, aux, sh_adam=sh_adam if (self.world > 1 and fused_sh) else None)
+                                                           sh_adam=sh_adam)
+        densify = None
+        if stats:
+            densify = (aux["dL_dmeans2D"], radii, self.xyz_gradient_accum, self.denom, self.max_radii2D)
+        self._adam_from_exchange(steps, 1.0, fused_sh, hold_opacity, densify)
+        return terms["loss"], color, radii
+
+    def _adam_from_exchange(self, steps, scale, sh_done, hold_opacity, densify):
+        """The optimiser kernels on the gradients the exchange holds (``scale`` turns sums over views into means)."""
+        it, o = self.iteration, self.opt
         g = self.exchange.shaped()
         m, v = self.state["xyz"]
         _C.adam_step(self.xyz, g["dL_dmeans3D"], m, v, self.xyz_lr(it), steps["xyz"], grad_scale=scale)
-        if not fused_sh:
+        if not sh_done:
             m, v = self.state["features"]
             _C.adam_step(self.features, g["dL_dsh"], m, v, o.feature_lr, steps["features"],
                          lr_tail=o.feature_lr / 20.0, period=3 * self.M, head=3, grad_scale=scale)
         names = ("opacity_raw", "scaling_raw", "rotation_raw")
-        densify = None
-        if stats:
-            densify = (aux["dL_dmeans2D"], radii, self.xyz_gradient_accum, self.denom, self.max_radii2D)
         # a held opacity takes a step of size zero (its moments are about to be cleared by the reset that asked for it)
         _C.adam_step_activated(
             tuple(getattr(self, n) for n in names),
@@ -299,6 +312,56 @@ class GaussianTrainer:
             (self._opacities, self._scales, self._rotations),
             (0.0 if hold_opacity else o.opacity_lr, o.scaling_lr, o.rotation_lr),
             tuple(max(steps[n], 1) for n in names), grad_scale=scale, densify=densify)
+
+    def _batched_step(self, cams, gts, bg, tanfovx, tanfovy, optimize, hold_opacity, collect_stats):
+        """One iteration whose loss is the mean over ``views_per_rank`` views on each of ``world`` ranks.  View k's
+        gradients (and statistics) leave for the other ranks as soon as its backward pass is queued and travel while
+        view k+1 is rendered; only the last view's exchange is exposed."""
+        V = self.views_per_rank
+        if V == 1 and not isinstance(cams, (list, tuple)):
+            cams, gts = [cams], [gts]
+        if not isinstance(cams, (list, tuple)) or len(cams) != V or len(gts) != V:
+            raise RuntimeError("this trainer steps %d views per rank and iteration" % V)
+        self.iteration += 1
+        o, ex = self.opt, self.exchange
+        stats = self.densify_stats and collect_stats
+        scene = self.scene_view()
+        terms = {}
+        for k, (cam, gt) in enumerate(zip(cams, gts)):
+            H, W = int(cam.image_height), int(cam.image_width)
+            if self._workspace is None or self._dL_dpix is None or self._dL_dpix.shape != (3, H, W):
+                self._workspace = torch.empty(_C.loss_workspace_floats(W, H), dtype=torch.float32,
+                                              device=self.xyz.device)
+                self._dL_dpix = torch.empty((3, H, W), dtype=torch.float32, device=self.xyz.device)
+
+            def loss_grad(color):
+                terms["loss"], dL = _C.l1_ssim_loss(color, gt, o.lambda_dssim, workspace=self._workspace,
+                                                    out=self._dL_dpix)
+                return dL
+
+            color, radii, aux = view_parallel.forward_backward(scene, cam, bg, loss_grad, ex, tanfovx, tanfovy, slot=k,
+                                                               max_radii2D=self.max_radii2D if stats else None)
+            ex.post_view(k, scene, cam, aux)
+        scale = 1.0 / (self.world * V)  # the batch loss is the mean over the views of all ranks
+        steps = self.adam_steps
+        factored = isinstance(ex, view_parallel.FactoredGradientExchange)
+        fused_sh = optimize and self.M == 16 and factored
+        sh_adam = None
+        if optimize:
+            for name in steps:
+                if not (hold_opacity and name == "opacity_raw"):
+                    steps[name] += 1
+        if fused_sh:  # inside the kernel that rebuilds the all-view SH gradient
+            m, v = self.state["features"]
+            sh_adam = dict(param=self.features, exp_avg=m, exp_avg_sq=v, lr_dc=o.feature_lr,
+                           lr_rest=o.feature_lr / 20.0, step=steps["features"], grad_scale=scale)
+        ex.finish(scene, sh_adam=sh_adam)
+        if stats and ex.stats:  # totals over every view of every rank
+            g = ex.shaped()
+            self.xyz_gradient_accum.add_(g["stat_norm"])
+            self.denom.add_(g["stat_vis"])
+        if optimize:
+            self._adam_from_exchange(steps, scale, fused_sh, hold_opacity, None)
         return terms["loss"], color, radii
 
     def _fused_step(self, cam, gt_image, bg, tanfovx, tanfovy, loss_grad, terms, hold_opacity, stats):

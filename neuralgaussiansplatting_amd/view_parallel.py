@@ -30,6 +30,8 @@ import torch.distributed as dist
 from .diff_gaussian_rasterization import _C
 
 BUCKET_FIELDS = ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations")
+# densification statistics in summable form (see ``_C.view_statistics``): they ride in the gradients' all-reduce
+STAT_FIELDS = ("stat_norm", "stat_vis")
 
 
 def _all_reduce_sum(t, group=None):
@@ -65,30 +67,65 @@ def _aligned_fields(names, sizes):
     return lay, off
 
 
-def bucket_layout(P, M):
+def bucket_layout(P, M, stats=False):
     """-> ({field: (offset, length)}, total) in float32 elements."""
-    return _aligned_fields(BUCKET_FIELDS, (3 * P, 3 * M * P, P, 3 * P, 4 * P))
+    names, sizes = BUCKET_FIELDS, (3 * P, 3 * M * P, P, 3 * P, 4 * P)
+    if stats:
+        names, sizes = names + STAT_FIELDS, sizes + (P, P)
+    return _aligned_fields(names, sizes)
+
+
+def _grouped(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
 class GradientBucket:
-    """One flat float32 buffer holding every parameter gradient of a step."""
+    """One flat float32 buffer holding every parameter gradient of a step, summed over the ranks by ONE all-reduce.
+
+    With ``stats`` the two densification-statistics rows travel in the same buffer.  With ``views_per_rank`` > 1
+    each view's backward pass writes into a second buffer of the same layout (``slot_views``) and ``post_view``
+    adds it to the bucket, so the step still ends with one all-reduce of one buffer."""
     skip_sh = False  # the backward pass produces dL_dsh itself
 
-    def __init__(self, P, M, device):
-        self.P, self.M = P, M
-        self.layout, total = bucket_layout(P, M)
+    def __init__(self, P, M, device, stats=False, views_per_rank=1):
+        self.P, self.M, self.stats, self.V = P, M, stats, int(views_per_rank)
+        self.layout, total = bucket_layout(P, M, stats)
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.views = {k: self.flat[o:o + n] for k, (o, n) in self.layout.items()}
+        if self.V > 1:
+            self.scratch = torch.zeros(total, dtype=torch.float32, device=device)
+            self._scratch_views = {k: self.scratch[o:o + n] for k, (o, n) in self.layout.items()}
+
+    def slot_views(self, slot=0):
+        """Where the backward pass of this rank's view ``slot`` writes its gradients."""
+        return self._scratch_views if self.V > 1 else self.views
 
     def shaped(self):
         P, M = self.P, self.M
         shapes = dict(dL_dmeans3D=(P, 3), dL_dsh=(P, M, 3), dL_dopacity=(P, 1), dL_dscales=(P, 3),
-                      dL_drotations=(P, 4))
+                      dL_drotations=(P, 4), stat_norm=(P, 1), stat_vis=(P, 1))
         return {k: v.view(shapes[k]) for k, v in self.views.items()}
+
+    def write_statistics(self, slot, dL_dmeans2D, radii, max_radii2D=None):
+        v = self.slot_views(slot)
+        _C.view_statistics(dL_dmeans2D, radii, v["stat_norm"], v["stat_vis"], max_radii2D)
+
+    def post_view(self, slot, scene=None, cam=None, aux=None, group=None):
+        """After the backward pass of view ``slot``: fold it into the step's sum."""
+        if self.V > 1:
+            if slot == 0:
+                self.flat.copy_(self.scratch)
+            else:
+                self.flat.add_(self.scratch)
+
+    def finish(self, scene=None, group=None, sh_adam=None):
+        if sh_adam is not None:
+            raise RuntimeError("the dense exchange has no fused SH optimiser step")
+        return self.all_reduce(group=group)
 
     def all_reduce(self, average=False, group=None, async_op=False):
         """Sum (or mean) the bucket over all ranks: the step's only collective."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not _grouped(group):
             return None
         if async_op:
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -97,12 +134,13 @@ class GradientBucket:
             self.flat.div_(dist.get_world_size(group))
         return None
 
+    def bytes_sent_per_rank(self):
+        return 4 * self.flat.numel()
 
     def reduce(self, scene=None, cam=None, aux=None, group=None, sh_adam=None):
-        """Uniform entry point of both exchange forms (the dense one needs none of the arguments)."""
-        if sh_adam is not None:
-            raise RuntimeError("the dense exchange has no fused SH optimiser step")
-        return self.all_reduce(group=group)
+        """One-view steps: ``post_view(0)`` and ``finish`` in one call (the dense form needs none of the arguments)."""
+        self.post_view(0)
+        return self.finish(scene, group, sh_adam)
 
 
 REDUCED_FIELDS = ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")
@@ -111,108 +149,147 @@ REDUCED_FIELDS = ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")
 class FactoredGradientExchange:
     """Gradient exchange with the SH part factored into (masked colour gradient, camera position) per view.
 
-    ``views`` are the backward pass's output slices (``skip_sh`` tells it not to produce dL_dsh);
-    ``reduce(scene, cam, aux)`` runs the exchange; afterwards ``shaped()`` holds the all-view sums."""
+    A rank renders ``views_per_rank`` views per step.  View k's backward pass writes into ``slot_views(k)``
+    (``skip_sh`` tells it not to produce dL_dsh); ``post_view(k, ...)`` queues that view's two collectives without
+    waiting for them, so they travel while view k+1 is rendered; ``finish(scene)`` waits, adds the views up and
+    rebuilds the SH gradient from all world x views_per_rank views.  Afterwards ``shaped()`` holds the sums over
+    every view of every rank.  ``reduce(scene, cam, aux)`` = ``post_view(0, ...)`` + ``finish(...)`` for one view
+    per rank."""
     skip_sh = True
 
-    def __init__(self, P, M, device, world_size=None, group=None):
-        self.P, self.M, self.group = P, M, group
+    def __init__(self, P, M, device, world_size=None, group=None, stats=False, views_per_rank=1):
+        self.P, self.M, self.group, self.stats, self.V = P, M, group, stats, int(views_per_rank)
         if world_size is None:
             world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.world = world_size
-        lay, total = _aligned_fields(REDUCED_FIELDS, (3 * P, P, 3 * P, 4 * P))
-        self.reduced = torch.zeros(total, dtype=torch.float32, device=device)
-        self.views = {name: self.reduced[off:off + n] for name, (off, n) in lay.items()}
+        names, sizes = REDUCED_FIELDS, (3 * P, P, 3 * P, 4 * P)
+        if stats:
+            names, sizes = names + STAT_FIELDS, sizes + (P, P)
+        self.layout, total = _aligned_fields(names, sizes)
+        V = self.V
+        # one buffer per view in flight; `reduced` is where the step's total ends up (view 0's own buffer for V == 1)
+        self.per_view = torch.zeros((V, total), dtype=torch.float32, device=device)
+        self.reduced = self.per_view[0] if V == 1 else torch.zeros(total, dtype=torch.float32, device=device)
+        self.views = {name: self.reduced[off:off + n] for name, (off, n) in self.layout.items()}
+        self._slot_views = [{name: self.per_view[k, off:off + n] for name, (off, n) in self.layout.items()}
+                            for k in range(V)]
         # one view's contribution: masked colour gradient [P,3], camera position, padding to whole 16 bytes
         self.row = ((3 * P + 3) + 3) & ~3
-        self.local = torch.zeros(self.row, dtype=torch.float32, device=device)
-        self.gathered = torch.zeros((self.world, self.row), dtype=torch.float32, device=device)
+        self.local = torch.zeros((V, self.row), dtype=torch.float32, device=device)
+        self.gathered = torch.zeros((V, self.world, self.row), dtype=torch.float32, device=device)
         self.dL_dsh = torch.empty((P, M, 3), dtype=torch.float32, device=device)
         # The masked colour gradient is final once the compositing backward has run; the backward pass hands it
         # over at that point (``early_color``) and the all-gather starts while the per-Gaussian stage still runs.
         self._on_gpu = torch.device(device).type == "cuda"
-        self._color_event = torch.cuda.Event() if self._on_gpu else None
+        self._color_event = [torch.cuda.Event() for _ in range(V)] if self._on_gpu else None
         self._side = torch.cuda.Stream(device=device) if self._on_gpu else None
-        self._early = False
+        self._early = [False] * V
+        self._pending = []
+        self._slot = 0
 
-    def begin_view(self, cam):
-        """Called before the backward pass of this rank's view: stores the camera position in the row that will
-        be gathered and returns the ``early_color`` argument of ``_C.rasterize_gaussians_backward``."""
+    def slot_views(self, slot=0):
+        return self._slot_views[slot]
+
+    def begin_view(self, cam, slot=0):
+        """Called before the backward pass of this rank's view ``slot``: stores the camera position in the row that
+        will be gathered and returns the ``early_color`` argument of ``_C.rasterize_gaussians_backward``."""
         P = self.P
-        self.local[3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
+        self.local[slot, 3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
         if not self._on_gpu:
             return None
-        self._early = False
-        return (self.local[:3 * P], self._color_ready)
+        self._early[slot] = False
+        self._slot = slot
+        return (self.local[slot, :3 * P], self._color_ready)
 
     def _color_ready(self):
-        self._color_event.record(torch.cuda.current_stream(self.local.device))
-        self._early = True
+        k = self._slot
+        self._color_event[k].record(torch.cuda.current_stream(self.local.device))
+        self._early[k] = True
 
     def shaped(self):
         P = self.P
-        shapes = dict(dL_dmeans3D=(P, 3), dL_dopacity=(P, 1), dL_dscales=(P, 3), dL_drotations=(P, 4))
+        shapes = dict(dL_dmeans3D=(P, 3), dL_dopacity=(P, 1), dL_dscales=(P, 3), dL_drotations=(P, 4),
+                      stat_norm=(P, 1), stat_vis=(P, 1))
         out = {k: v.view(shapes[k]) for k, v in self.views.items()}
         out["dL_dsh"] = self.dL_dsh
         return out
 
     def bytes_sent_per_rank(self):
-        """Payload each rank contributes to the two collectives (float32 bytes)."""
-        return 4 * (self.row + self.reduced.numel())
+        """Payload each rank contributes to the collectives of one step (float32 bytes)."""
+        return 4 * self.V * (self.row + self.per_view.shape[1])
 
-    def reduce(self, scene, cam, aux, group=None, sh_adam=None):
-        """``aux`` is what ``forward_backward`` returned for this rank's view (it carries the geometry buffer with
-        the clamp flags and the raw colour gradient).  With ``sh_adam`` (see ``_C.sh_gradient_from_views``) the
-        rebuilt SH gradient is consumed by the coefficients' Adam step on the spot and ``shaped()['dL_dsh']`` is
-        not updated."""
+    def write_statistics(self, slot, dL_dmeans2D, radii, max_radii2D=None):
+        v = self._slot_views[slot]
+        _C.view_statistics(dL_dmeans2D, radii, v["stat_norm"], v["stat_vis"], max_radii2D)
+
+    def post_view(self, slot, scene, cam, aux, group=None):
+        """``aux`` is what ``forward_backward`` returned for this view (it carries the geometry buffer with the
+        clamp flags and the raw colour gradient).  Queues the view's all-gather and all-reduce; with RCCL neither
+        is waited for here."""
         group = group if group is not None else self.group
         P = self.P
-        early, self._early = self._early, False
+        early, self._early[slot] = self._early[slot], False
         if not early:  # the backward pass was not given begin_view()'s hand-over: derive the row now
-            _C.masked_color_gradient(aux["geom"], aux["dL_dcolors"], out=self.local[:3 * P])
-            self.local[3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
-        pending = None
+            _C.masked_color_gradient(aux["geom"], aux["dL_dcolors"], out=self.local[slot, :3 * P])
+            self.local[slot, 3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
         grouped = dist.is_available() and dist.is_initialized()
         if grouped and dist.get_backend(group) == "nccl":  # also with a single rank: same calls, trivial traffic
-            # both collectives are queued at once; the SH rebuild below needs only the gather, so it runs while the
-            # all-reduce of the other gradients is still on the wire
             if early:
                 # the gather waits for the hand-over event only, not for the per-Gaussian stage queued behind it
-                self._side.wait_event(self._color_event)
+                self._side.wait_event(self._color_event[slot])
                 with torch.cuda.stream(self._side):
-                    gather = dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=group,
+                    gather = dist.all_gather_into_tensor(self.gathered[slot].view(-1), self.local[slot], group=group,
                                                          async_op=True)
             else:
-                gather = dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=group, async_op=True)
-            pending = dist.all_reduce(self.reduced, op=dist.ReduceOp.SUM, group=group, async_op=True)
-            gather.wait()
-            gathered = self.gathered
+                gather = dist.all_gather_into_tensor(self.gathered[slot].view(-1), self.local[slot], group=group,
+                                                     async_op=True)
+            self._pending.append(gather)
+            self._pending.append(dist.all_reduce(self.per_view[slot], op=dist.ReduceOp.SUM, group=group,
+                                                 async_op=True))
         elif self.world > 1:
-            _all_gather_rows(self.gathered, self.local, group)
-            _all_reduce_sum(self.reduced, group)
-            gathered = self.gathered
+            _all_gather_rows(self.gathered[slot], self.local[slot], group)
+            _all_reduce_sum(self.per_view[slot], group)
         else:
-            gathered = self.local.view(1, self.row)
-        _C.sh_gradient_from_views(scene.means3D, gathered[:, 3 * P:3 * P + 3], gathered[:, :3 * P], scene.sh_degree,
-                                  self.M, out=self.dL_dsh, sh_adam=sh_adam)
-        if pending is not None:
-            pending.wait()
+            self.gathered[slot, 0].copy_(self.local[slot])
+
+    def finish(self, scene, group=None, sh_adam=None):
+        """Waits for the queued collectives, adds the views of the step up and rebuilds the summed SH gradient
+        (views in (slot, rank) order: identical bits on every rank).  With ``sh_adam`` (see
+        ``_C.sh_gradient_from_views``) that gradient is consumed by the coefficients' Adam step on the spot and
+        ``shaped()['dL_dsh']`` is not updated."""
+        P = self.P
+        for work in self._pending:
+            work.wait()
+        self._pending = []
+        if self.V > 1:
+            torch.sum(self.per_view, dim=0, out=self.reduced)
+        rows = self.gathered.view(self.V * self.world, self.row)
+        _C.sh_gradient_from_views(scene.means3D, rows[:, 3 * P:3 * P + 3], rows[:, :3 * P], scene.sh_degree, self.M,
+                                  out=self.dL_dsh, sh_adam=sh_adam)
         return None
 
+    def reduce(self, scene, cam, aux, group=None, sh_adam=None):
+        self.post_view(0, scene, cam, aux, group)
+        return self.finish(scene, group, sh_adam)
 
-def sync_densification_stats(xyz_gradient_accum, denom, max_radii2D, group=None):
+
+def sync_densification_stats(xyz_gradient_accum, denom, max_radii2D, group=None, sums=True):
     """Merge the per-rank densification statistics in place, right before they are used: the view-space gradient
     norms and the visibility counts (scene/gaussian_model.py:550-552) add up over the ranks' views, the largest
     screen radius (train.py:115) is the maximum.  Afterwards every rank holds the totals over all views seen since
     the last reset, so identical densification decisions follow; reset the statistics afterwards as the reference
-    does (gaussian_model.py:455-457) -- merging twice without a reset would count the views twice."""
+    does (gaussian_model.py:455-457) -- merging twice without a reset would count the views twice.
+    ``sums=False``: the two sums already travelled with the gradients of every step (``stats`` of the exchange
+    classes) and every rank holds their totals; only the maximum, which may be merged at any time with the same
+    result, is left to do."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    sums = torch.cat([xyz_gradient_accum.reshape(-1), denom.reshape(-1)])
-    _all_reduce_sum(sums, group)
-    n = xyz_gradient_accum.numel()
-    xyz_gradient_accum.copy_(sums[:n].view_as(xyz_gradient_accum))
-    denom.copy_(sums[n:].view_as(denom))
+    if sums:
+        both = torch.cat([xyz_gradient_accum.reshape(-1), denom.reshape(-1)])
+        _all_reduce_sum(both, group)
+        n = xyz_gradient_accum.numel()
+        xyz_gradient_accum.copy_(both[:n].view_as(xyz_gradient_accum))
+        denom.copy_(both[n:].view_as(denom))
     if max_radii2D.is_cuda and dist.get_backend(group) != "nccl":
         h = max_radii2D.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
@@ -227,12 +304,15 @@ def shard_views(num_views, rank, world_size):
 
 
 def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale_modifier=1.0, debug=False,
-                     sh_adam=None):
+                     sh_adam=None, slot=0, max_radii2D=None):
     """One pass of the hot path for one view on this rank's GPU: rasterize,
     obtain dL/dpixel from ``dL_dpix_fn(color)``, run the backward pass with the
-    parameter gradients landing in ``bucket`` (either exchange form; ``bucket.reduce(scene, cam, aux)`` then
-    sums them over the ranks).  ``sh_adam`` (see ``_C.rasterize_gaussians_backward``) makes the backward pass
-    apply the SH coefficients' optimiser step itself; single-rank steps only.  Returns (color, radii, aux)."""
+    parameter gradients landing in ``bucket.slot_views(slot)`` (either exchange form;
+    ``bucket.post_view(slot, scene, cam, aux)`` then queues their exchange and ``bucket.finish(scene)`` completes
+    the step; ``bucket.reduce(scene, cam, aux)`` does both for one view per rank).  ``sh_adam`` (see
+    ``_C.rasterize_gaussians_backward``) makes the backward pass apply the SH coefficients' optimiser step itself;
+    single-rank single-view steps only.  A bucket built with ``stats`` also receives the view's densification
+    statistics (and ``max_radii2D`` its running maximum).  Returns (color, radii, aux)."""
     e = torch.empty(0)
     H, W = int(cam.image_height), int(cam.image_width)
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(
@@ -240,9 +320,12 @@ def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale
         cam.world_view_transform, cam.full_proj_transform, tanfovx, tanfovy, H, W, scene.shs, scene.sh_degree,
         cam.camera_center, False, debug)
     dL_dpix = dL_dpix_fn(color)
-    early = bucket.begin_view(cam) if sh_adam is None and hasattr(bucket, "begin_view") else None
+    early = bucket.begin_view(cam, slot) if sh_adam is None and hasattr(bucket, "begin_view") else None
+    out = {k: v for k, v in bucket.slot_views(slot).items() if k not in STAT_FIELDS}
     res = _C.rasterize_gaussians_backward(
         bg, scene.means3D, radii, e, scene.scales, scene.rotations, scale_modifier, e, cam.world_view_transform,
         cam.full_proj_transform, tanfovx, tanfovy, dL_dpix, scene.shs, scene.sh_degree, cam.camera_center, geom, R,
-        binning, img, debug, out=bucket.views, skip_sh=bucket.skip_sh, sh_adam=sh_adam, early_color=early)
+        binning, img, debug, out=out, skip_sh=bucket.skip_sh, sh_adam=sh_adam, early_color=early)
+    if getattr(bucket, "stats", False):
+        bucket.write_statistics(slot, res[0], radii, max_radii2D)
     return color, radii, dict(num_rendered=R, dL_dmeans2D=res[0], dL_dcolors=res[1], dL_dcov3D=res[4], geom=geom)

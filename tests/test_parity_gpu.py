@@ -734,11 +734,11 @@ def test_view_factored_sh_gradient_equals_sum_of_per_view_gradients(D, M, P, dgr
                                                     c["tanfovy"])
         # the backward pass handed the masked colour gradient over between its two stages: same bits as masking
         # that run's dL_dcolors afterwards, and the camera position sits behind it
-        assert fact._early
-        assert torch.equal(fact.local[:3 * P], dgr._C.masked_color_gradient(aux2["geom"], aux2["dL_dcolors"]).reshape(-1))
-        assert torch.equal(fact.local[3 * P:3 * P + 3], cam.camera_center.reshape(3))
+        assert fact._early[0]
+        assert torch.equal(fact.local[0, :3 * P], dgr._C.masked_color_gradient(aux2["geom"], aux2["dL_dcolors"]).reshape(-1))
+        assert torch.equal(fact.local[0, 3 * P:3 * P + 3], cam.camera_center.reshape(3))
         fact.reduce(scene, cam, aux2)
-        assert not fact._early
+        assert not fact._early[0]
         torch.cuda.synchronize()
         f = fact.shaped()
         for name in view_parallel.BUCKET_FIELDS:
@@ -794,6 +794,35 @@ def _rccl_single_rank_worker(rank, port, ret):
             for name, want in dense.shaped().items():
                 got = ex.shaped()[name]
                 ok = ok and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-12
+        # two views per rank and step, statistics riding along: view 0's collectives are in flight while view 1 is
+        # rendered; the step's result is the sum of the two views' gradients and statistics
+        cams = [cam, make_camera(W, H, synthetic.FOVX, (-1.9, 0.4, -3.4), device=dev)]
+        dLs = [dL, torch.randn(3, H, W, generator=torch.Generator().manual_seed(4)).to(dev)]
+        want, want_stats, want_max = None, None, torch.zeros(P, dtype=torch.int32, device=dev)
+        for c, g in zip(cams, dLs):
+            dense = view_parallel.GradientBucket(P, M, dev)
+            _, radii, aux = view_parallel.forward_backward(sc, c, bg, lambda _c: g, dense, tanx, tany)
+            vis = radii > 0
+            st = torch.stack([torch.where(vis, aux["dL_dmeans2D"][:, :2].norm(dim=1), torch.zeros(())), vis.float()])
+            want_stats = st if want_stats is None else want_stats + st
+            want_max = torch.maximum(want_max, radii)
+            d = {k: v.clone() for k, v in dense.shaped().items()}
+            want = d if want is None else {k: want[k] + d[k] for k in d}
+        for cls in (view_parallel.FactoredGradientExchange, view_parallel.GradientBucket):
+            ex = cls(P, M, dev, stats=True, views_per_rank=2)
+            got_max = torch.zeros(P, dtype=torch.int32, device=dev)
+            for k, (c, g) in enumerate(zip(cams, dLs)):
+                _, _, aux = view_parallel.forward_backward(sc, c, bg, lambda _c: g, ex, tanx, tany, slot=k,
+                                                           max_radii2D=got_max)
+                ex.post_view(k, sc, c, aux)
+            ex.finish(sc)
+            torch.cuda.synchronize()
+            got = ex.shaped()
+            for name in want:
+                ok = ok and float((got[name] - want[name]).abs().max()) <= 2e-5 * float(want[name].abs().max()) + 1e-12
+            ok = ok and torch.allclose(got["stat_norm"].reshape(-1), want_stats[0], rtol=1e-4, atol=1e-12)
+            ok = ok and torch.equal(got["stat_vis"].reshape(-1), want_stats[1]) and torch.equal(got_max, want_max)
+            ok = ok and ex.bytes_sent_per_rank() > 0
         ret[0] = bool(ok)
     finally:
         dist.destroy_process_group()

@@ -262,9 +262,10 @@ def test_training_fits_a_rendered_target(C):
     assert all(torch.isfinite(t).all() for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw))
 
 
-def _two_rank_trainer_worker(rank, port, exchange, ret):
-    """Two gloo ranks sharing the one GPU: each trains on its own view; the gradient exchange (factored or dense)
-    must leave both parameter replicas bit-identical."""
+def _two_rank_trainer_worker(rank, port, exchange, views, ret):
+    """Two gloo ranks sharing the one GPU: each trains on its own view(s); the gradient exchange (factored or
+    dense, one or two views per rank and step) must leave both parameter replicas bit-identical, and every rank
+    must hold the same totals of the densification statistics without a separate merge of the sums."""
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -274,13 +275,23 @@ def _two_rank_trainer_worker(rank, port, exchange, ret):
     try:
         P, W, H, D = 2500, 96, 64, 3
         sc = synthetic.make_scene(P, D, (-3.8, -3.0), (1.3, 1.3, 1.3), seed=8, sh_coeffs=16)
-        cam = make_camera(W, H, synthetic.FOVX, ((0.7, 0.5, -4.0), (-1.8, 0.4, -3.5))[rank], device=DEV)
-        gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(60 + rank)).to(DEV)
+        eyes = ((0.7, 0.5, -4.0), (-1.8, 0.4, -3.5), (1.6, -0.3, -3.7), (-0.4, 0.9, -3.9))
+        cams = [make_camera(W, H, synthetic.FOVX, eyes[rank * views + k], device=DEV) for k in range(views)]
+        gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(60 + rank * views + k)).to(DEV)
+               for k in range(views)]
         bg = torch.zeros(3, device=DEV)
-        tr = train_step.GaussianTrainer(sc, DEV, factored_exchange=exchange == "factored")
+        tr = train_step.GaussianTrainer(sc, DEV, factored_exchange=exchange == "factored", views_per_rank=views)
+        assert tr.exchange.stats and not tr.fused
+        cam = cams[0]
         for _ in range(3):
-            tr.step(cam, gt, bg, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5))
-        tr.sync_densification_stats()
+            tr.step(cams if views > 1 else cam, gts if views > 1 else gts[0], bg, math.tan(cam.FoVx * 0.5),
+                    math.tan(cam.FoVy * 0.5))
+        torch.cuda.synchronize()
+        # the sums are global already; a Gaussian is counted once per view of either rank that rendered it
+        seen = float(tr.denom.max())
+        assert 0 < seen <= 3 * 2 * views
+        tr.sync_densification_stats()  # merges the largest radius only
+        assert float(tr.denom.max()) == seen
         torch.cuda.synchronize()
         state = [t.detach().cpu() for t in (tr.xyz, tr.features, tr.opacity_raw, tr.scaling_raw, tr.rotation_raw,
                                             tr.xyz_gradient_accum, tr.denom, tr.max_radii2D.float())]
@@ -293,15 +304,43 @@ def _two_rank_trainer_worker(rank, port, exchange, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["factored", "dense"])
-def test_two_rank_training_keeps_replicas_identical(exchange, C):
+@pytest.mark.parametrize("exchange,views", [("factored", 1), ("dense", 1), ("factored", 2), ("dense", 2)])
+def test_two_rank_training_keeps_replicas_identical(exchange, views, C):
     import os
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 35500 + os.getpid() % 2000 + (7 if exchange == "dense" else 0)
-    mp.spawn(_two_rank_trainer_worker, args=(port, exchange, ret), nprocs=2, join=True)
+    port = 35500 + os.getpid() % 2000 + (7 if exchange == "dense" else 0) + 13 * views
+    mp.spawn(_two_rank_trainer_worker, args=(port, exchange, views, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_view_batches_on_one_rank_match_both_exchange_forms(C):
+    """Two views per step on ONE rank (no process group): the factored and the dense bookkeeping must take the same
+    training trajectory (up to the rounding of float atomics), and the statistics must count both views."""
+    P, W, H, D = 3000, 128, 80, 3
+    sc = synthetic.make_scene(P, D, (-3.8, -3.0), (1.3, 1.3, 1.3), seed=9, sh_coeffs=16)
+    cams = [make_camera(W, H, synthetic.FOVX, e, device=DEV) for e in ((0.7, 0.5, -4.0), (-1.8, 0.4, -3.5))]
+    gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(80 + k)).to(DEV) for k in range(2)]
+    bg = torch.zeros(3, device=DEV)
+    tanx, tany = math.tan(cams[0].FoVx * 0.5), math.tan(cams[0].FoVy * 0.5)
+    trs = [train_step.GaussianTrainer(sc, DEV, factored_exchange=f, views_per_rank=2) for f in (True, False)]
+    for tr in trs:
+        assert tr.batched and not tr.fused
+        for _ in range(3):
+            tr.step(cams, gts, bg, tanx, tany)
+    a, b = trs
+    lr_of = dict(xyz=a.opt.position_lr_init, features=a.opt.feature_lr, opacity_raw=a.opt.opacity_lr,
+                 scaling_raw=a.opt.scaling_lr, rotation_raw=a.opt.rotation_lr)
+    for n, lr in lr_of.items():
+        diff = (getattr(a, n) - getattr(b, n)).abs()
+        assert float((diff <= 1e-3 * lr).float().mean()) > 0.995, n
+        assert float(diff.max()) <= 6.5 * lr, n
+    assert torch.equal(a.denom, b.denom) and float(a.denom.max()) == 6.0
+    assert torch.equal(a.max_radii2D, b.max_radii2D) and int(a.max_radii2D.max()) > 0
+    assert torch.allclose(a.xyz_gradient_accum, b.xyz_gradient_accum, rtol=1e-3, atol=1e-9)
+    with pytest.raises(RuntimeError):
+        a.step(cams[0], gts[0], bg, tanx, tany)
 
 
 # ---- densification, pruning, opacity reset -----------------------------------------------------------------------
@@ -811,8 +850,12 @@ def test_fused_training_equals_separate_optimiser_kernels(C, config):
                 assert float((ma - mb).abs().max()) <= 1e-3 * big + 1e-20, (it, n)
         if hold:
             assert a.adam_steps == b.adam_steps and a.adam_steps["opacity_raw"] == it
-    assert torch.equal(a.denom, b.denom) and torch.equal(a.max_radii2D, b.max_radii2D)
-    assert torch.allclose(a.xyz_gradient_accum, b.xyz_gradient_accum, rtol=1e-3, atol=1e-9)
+    # the two trajectories drift apart by rounding-level gradient differences amplified by Adam's first steps (see
+    # above), so a few Gaussians may cross a visibility or radius threshold on one side only
+    assert float((a.denom == b.denom).float().mean()) > 0.999
+    assert float((a.max_radii2D == b.max_radii2D).float().mean()) > 0.99
+    rel = (a.xyz_gradient_accum - b.xyz_gradient_accum).abs() / (b.xyz_gradient_accum.abs() + 1e-7)
+    assert float((rel < 2e-2).float().mean()) > 0.99
     # the activated copies follow on demand
     op, scl, rot = C.activate_parameters(a.opacity_raw, a.scaling_raw, a.rotation_raw)
     assert torch.equal(a.opacities, op) and torch.equal(a.scales, scl) and torch.equal(a.rotations, rot)

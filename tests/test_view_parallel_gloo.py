@@ -104,6 +104,70 @@ def _factored_worker(rank, world, port, P, M, D, ret):
         dist.destroy_process_group()
 
 
+def _multi_view_worker(rank, world, port, P, M, D, V, ret):
+    """V views per rank and step with the statistics rows riding along: every view's buffers go through their own
+    collectives, the step's result is the sum over all world x V views, the SH rebuild sees the views in
+    (slot, rank) order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def masked(geom, dL_dcolors, out=None):
+            out.copy_((dL_dcolors * geom).reshape(-1))
+            return out
+
+        seen = {}
+
+        def sh_from_views(means3D, campos, colors, degree, M_, out=None, sh_adam=None):
+            assert campos.shape == (V * world, 3) and colors.shape == (V * world, 3 * P)
+            seen["campos"] = campos.clone()
+            out.copy_(_sh_sum(means3D, campos, colors, degree, M_))
+            return out
+
+        view_parallel._C.masked_color_gradient = masked
+        view_parallel._C.sh_gradient_from_views = sh_from_views
+        means = torch.randn(P, 3, generator=torch.Generator().manual_seed(7))
+        scene = _Obj()
+        scene.means3D, scene.sh_degree = means, D
+        fill = lambda v, r, k, i: v.copy_(torch.arange(v.numel(), dtype=torch.float32) * (r * V + k + 1) + i)
+        ok = True
+        for cls in (view_parallel.FactoredGradientExchange, view_parallel.GradientBucket):
+            ex = cls(P, M, torch.device("cpu"), stats=True, views_per_rank=V)
+            for k in range(V):
+                colors, mask, campos = _view_inputs(rank * V + k, P)
+                cam = _Obj()
+                cam.camera_center = campos
+                if hasattr(ex, "begin_view"):
+                    assert ex.begin_view(cam, k) is None  # no hand-over on CPU tensors
+                for i, (name, v) in enumerate(ex.slot_views(k).items()):
+                    fill(v, rank, k, i)
+                ex.post_view(k, scene, cam, dict(geom=mask, dL_dcolors=colors))
+            ex.finish(scene)
+            n_views = world * V
+            names = list(ex.slot_views(0))
+            assert set(view_parallel.STAT_FIELDS) <= set(names)
+            sh = ex.shaped()
+            for i, name in enumerate(names):
+                v = ex.views[name]
+                want = torch.arange(v.numel(), dtype=torch.float32) * (n_views * (n_views + 1) // 2) + i * n_views
+                ok = ok and torch.equal(v, want) and sh[name].shape[0] == P
+            if cls is view_parallel.FactoredGradientExchange:
+                order = [(k, r) for k in range(V) for r in range(world)]
+                allv = [_view_inputs(r * V + k, P) for k, r in order]
+                ok = ok and torch.equal(seen["campos"], torch.stack([a[2] for a in allv]))
+                want_sh = _sh_sum(means, torch.stack([a[2] for a in allv]),
+                                  torch.stack([(a[0] * a[1]).reshape(-1) for a in allv]), D, M)
+                ok = ok and torch.equal(sh["dL_dsh"], want_sh)
+                up4 = lambda n: (n + 3) & ~3
+                per_view = up4(3 * P + 3) + up4(3 * P) + up4(P) + up4(3 * P) + 4 * P + 2 * up4(P)
+                ok = ok and ex.bytes_sent_per_rank() == 4 * V * per_view
+            else:
+                ok = ok and ex.bytes_sent_per_rank() == 4 * ex.flat.numel()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
 def _densify_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -117,6 +181,11 @@ def _densify_worker(rank, world, port, ret):
         view_parallel.sync_densification_stats(acc, den, rad)
         every = [mk(r) for r in range(world)]
         ok = torch.equal(acc, sum(e[0] for e in every)) and torch.equal(den, sum(e[1] for e in every))
+        ok = ok and torch.equal(rad, torch.stack([e[2] for e in every]).max(dim=0).values)
+        # sums that already travelled with the gradients are left alone; the maximum is still merged
+        acc, den, rad = mk(rank)
+        view_parallel.sync_densification_stats(acc, den, rad, sums=False)
+        ok = ok and torch.equal(acc, mk(rank)[0]) and torch.equal(den, mk(rank)[1])
         ok = ok and torch.equal(rad, torch.stack([e[2] for e in every]).max(dim=0).values)
         ret[rank] = bool(ok)
     finally:
@@ -140,6 +209,15 @@ def test_factored_exchange_world2():
     ret = mgr.dict()
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_factored_worker, args=(world, port, P, M, D, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_two_views_per_rank_with_statistics_world2():
+    world, P, M, D, V = 2, 29, 16, 3, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_multi_view_worker, args=(world, port, P, M, D, V, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
 
