@@ -287,9 +287,9 @@ void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_
 }
 
 void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* keys, int T,
-                            uint2* ranges)
+                            uint2* ranges, size_t clear_bytes)
 {
-    (void)hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s);
+    (void)hipMemsetAsync(ranges, 0, clear_bytes > (size_t)T * sizeof(uint2) ? clear_bytes : (size_t)T * sizeof(uint2), s);
     if (capacity > 0 && (uintptr_t)keys % 16 == 0)
         hipLaunchKernelGGL(tile_ranges_vec_kernel, dim3((unsigned)((capacity + 1023) / 1024)), dim3(256), 0, s, count,
                            capacity, keys, ranges);

@@ -351,14 +351,15 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     const int in_buf = ngs_sort_input_buffer(tile_bits);
     uint2* ranges = (uint2*)(ib + il.ranges);
     // Where the depth order comes from (both give the same lists): a sort of the P Gaussians before their instances
-    // are emitted -- 14 small launches whose cost follows P -- or a sort of every tile's list afterwards -- three
+    // are emitted -- 14 small launches whose cost follows P -- or a sort of every tile's list afterwards -- two
     // launches whose cost follows the instance count and rises steeply once lists outgrow a workgroup (4096
     // entries).  Measured on MI355X the first costs about 90 us + 48 us per million Gaussians, the second about
-    // 25 us + 14 us per million instances while lists are short.
+    // 12 us + 10.5 us per million instances while lists are short (0.13 ms at 1500 per tile and 12 M instances,
+    // 0.19 ms at 2000 and 16.5 M, 0.53 ms at 2900 and 24 M, where the first lists pass 4096 entries).
     bool depth_first;
     {
         const double inst = (double)capacity, per_tile = inst / (double)T;
-        const double by_tile = 25.0 + 14e-6 * inst * (per_tile > 1500.0 ? 1.0 + (per_tile - 1500.0) / 1500.0 : 1.0);
+        const double by_tile = 12.0 + 10.5e-6 * inst * (per_tile > 2000.0 ? 1.0 + (per_tile - 2000.0) / 700.0 : 1.0);
         const double by_gaussian = 90.0 + 48e-6 * (double)P;
         depth_first = by_gaussian < by_tile;
         if (g_depth_order_choice >= 0) depth_first = g_depth_order_choice != 0;
@@ -398,12 +399,13 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
             NGS_STAGE("sort");
         }
         prof_begin(ps, ST_RANGES, st);
-        ngs_launch_tile_ranges(st, misc, capacity, tkeys[0], T, ranges);
+        // the same fill also clears the counter of the per-tile sort's work list, which follows the ranges
+        ngs_launch_tile_ranges(st, misc, capacity, tkeys[0], T, ranges, il.hard + 16 - il.ranges);
         prof_end(ps, ST_RANGES, st);
         NGS_STAGE("identifyTileRanges");
         if (capacity > 0 && !depth_first) {
             prof_begin(ps, ST_SEGSORT, st);
-            ngs_launch_sort_segments(st, T, ranges, depth, tkeys, vals);
+            ngs_launch_sort_segments(st, T, ranges, depth, tkeys, vals, (uint32_t*)(ib + il.hard));
             prof_end(ps, ST_SEGSORT, st);
             NGS_STAGE("sort (depth)");
         }

@@ -56,6 +56,7 @@ struct ImageLayout {
     size_t final_T;   // float[T*256] tile-major: pixel (tile, ly*16+lx)
     size_t n_contrib; // u32  [T*256] tile-major
     size_t ranges;    // uint2[T]
+    size_t hard;      // u32[4 + 2T]: work lists of the per-tile sort's later launches; [0], [1] = lengths, list k at 4 + kT
     size_t total;
 };
 
@@ -64,8 +65,8 @@ struct ImageLayout {
 // the capacity: that is all the backward pass needs from this buffer.
 struct BinLayout {
     size_t vals[2];  // u32[C] ping/pong; vals[0] (offset 0) is the sorted point list
-    size_t keys[2];  // u32[C] each: tile ids, ping/pong of the tile-level sort (then depth-key scratch of the per-tile
-                     // sort of long lists)
+    size_t keys[2];  // u32[C] each: tile ids, ping/pong of the tile-level sort (then depth-bit scratch of the general
+                     // per-tile sort)
     size_t hist;     // u32[256 * sort_blocks(C)] digit-major per-block histogram
     size_t totals;   // u32[256] per-digit totals
     size_t total;
@@ -111,6 +112,7 @@ static inline ImageLayout ngs_image_layout(int W, int H)
     l.final_T = o; o = ngs_align_up(o + T * NGS_TILE_PIX * 4);
     l.n_contrib = o; o = ngs_align_up(o + T * NGS_TILE_PIX * 4);
     l.ranges = o; o = ngs_align_up(o + T * 8);
+    l.hard = o; o = ngs_align_up(o + (2 * T + 4) * 4);
     l.total = o + NGS_ALIGN;
     return l;
 }
@@ -232,8 +234,9 @@ void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const u
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
                           const uint32_t* order, int grid_x, uint32_t* tile_keys, uint32_t* vals, int64_t capacity,
                           uint32_t* misc);
+// clear_bytes: bytes to zero starting at `ranges` (at least 8 T; the caller extends it over the counter that follows)
 void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* tile_keys, int T,
-                            uint2* ranges);
+                            uint2* ranges, size_t clear_bytes);
 // radix_sort.hip: stable LSD radix sort of (32-bit key, 32-bit value) pairs on the low `bits` bits of the key,
 // result in keys[0]/vals[0].  It runs twice per frame: over the Gaussians' depth bits (all 32), and over the tile
 // ids of the instances emitted in that depth order -- stable, so every tile's list comes out sorted by depth.
@@ -243,9 +246,10 @@ int ngs_sort_input_buffer(int bits);
 void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
                                uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits);
 // Per-tile depth sort of vals[0] (lists in index order inside each tile) by the depth of the listed Gaussians;
-// keys[] and vals[1] are scratch for lists that do not fit a workgroup's registers.
+// keys[] and vals[1] are scratch for lists that do not fit a workgroup.
+// hard: u32[4 + 2T] with hard[0] == hard[1] == 0 on entry (see ImageLayout).
 void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
-                              uint32_t* const vals[2]);
+                              uint32_t* const vals[2], uint32_t* hard);
 // render_fwd.hip
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,

@@ -249,151 +249,214 @@ __device__ __forceinline__ void block_rank_pass(const uint32_t (&key)[ITEMS], in
     }
 }
 
-// Segments with min_n < n <= THREADS*ITEMS: the whole segment lives in registers, no global traffic between passes.
-// Longer segments get more threads rather than more items per thread: the passes are a chain of barriers, and a
-// workgroup's latency is what a launch with few such tiles waits for.
-template <int ITEMS, int THREADS>
-__global__ __launch_bounds__(THREADS) void segment_sort_small_kernel(const uint2* __restrict__ ranges, int min_n,
-                                                                     const float* __restrict__ depth,
-                                                                     uint32_t* __restrict__ vals0)
+// Per-tile sort, common case: lists whose depths are spread out.  One distribution step instead of four radix
+// passes: every entry goes to bucket (depth bits - smallest depth bits) >> s, with s chosen so that the tile's depth
+// range spans between NB/2 and NB buckets (the bit pattern of a positive float grows with its value, so buckets are
+// ordered by depth); buckets then hold a handful of entries each, and an entry's final place is its bucket's start
+// plus the number of bucket mates that precede it in (depth, position in the incoming list) order -- the stable
+// order by depth.  Five barriers per tile, 6 bytes of LDS per entry.
+// One workgroup per tile takes lists of up to SEG_ITEMS * THREADS entries (in < 0), or workgroups share out the
+// tiles of work list `in`.  A tile whose depths are all equal is sorted already.  Tiles a launch cannot take (longer
+// lists, or a bucket with more than SEG_BUCKET_LIMIT entries: many equal or nearly equal depths) are appended to
+// work list `out` for the next kernel.
+// work lists (see ImageLayout::hard): word 0 / 1 = length of list 0 / 1, list k at words 4 + k T.
+#define SEG_ITEMS 16
+#define SEG_BUCKET_LIMIT 128
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void segment_sort_bucket_kernel(int T, const uint2* __restrict__ ranges,
+                                                                      const float* __restrict__ depth,
+                                                                      uint32_t* __restrict__ vals0,
+                                                                      uint32_t* __restrict__ hard, int in, int out)
 {
-    constexpr int CAP = THREADS * ITEMS, WAVES = THREADS / 64;
-    __shared__ uint32_t s_cnt[WAVES][256];
-    __shared__ uint32_t s_start[256];
-    __shared__ uint32_t s_wtot[4];
-    __shared__ uint32_t s_red[2 * WAVES];
-    __shared__ uint32_t s_key[CAP];
-    __shared__ uint32_t s_val[CAP];
+    constexpr int CAP = SEG_ITEMS * THREADS, NB = 8 * THREADS, WAVES = THREADS / 64;
+    __shared__ uint32_t s_cnt[NB];   // bucket sizes, then each bucket's cursor (its end once all entries sit)
+    __shared__ uint32_t s_key[CAP];  // depth bits grouped by bucket
+    __shared__ uint16_t s_slot[CAP]; // and where in the incoming list each came from
+    __shared__ uint32_t s_red[3][WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint2 range = ranges[blockIdx.x];
-    const int n = (int)(range.y - range.x);
-    // block-uniform: another launch (or nobody: an empty tile, or a single entry, which is sorted) owns this tile
-    if (n <= min_n || n > CAP || n < 2) return;
-    const size_t lo = range.x;
-    const int quota = ((((n + WAVES - 1) / WAVES) + 63) / 64) * 64;  // slots per wave
-    uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
-    uint32_t k_or = 0u, k_and = ~0u;
+    const uint32_t n_work = in < 0 ? (uint32_t)T : hard[in];
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {  // one trip when every tile has its own workgroup
+        const uint32_t tile = in < 0 ? w : hard[4 + (size_t)in * T + w];
+        const uint2 range = ranges[tile];
+        const int n = (int)(range.y - range.x);
+        if (n < 2) continue;  // block-uniform, like every branch on n below
+        if (n > CAP) {
+            if (tid == 0) hard[4 + (size_t)out * T + atomicAdd(&hard[out], 1u)] = tile;
+            continue;
+        }
+        const size_t lo = range.x;
+        __syncthreads();  // a previous trip's readers of the LDS tables are done
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const int slot = wave * quota + i * 64 + lane;
-        const bool valid = i * 64 < quota && slot < n;
-        val[i] = valid ? vals0[lo + slot] : 0u;
-    }
-    // all list entries are on their way before the first dependent depth gather is issued
+        for (int j = 0; j < NB / THREADS; j++) s_cnt[j * THREADS + tid] = 0;
+        uint32_t key[SEG_ITEMS], val[SEG_ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const int slot = wave * quota + i * 64 + lane;
-        const bool valid = i * 64 < quota && slot < n;
-        key[i] = valid ? __float_as_uint(depth[val[i]]) : ~0u;
-        if (valid) { k_or |= key[i]; k_and &= key[i]; }
-    }
-    // bits that differ somewhere in the segment
+        for (int i = 0; i < SEG_ITEMS; i++) {
+            const int slot = i * THREADS + tid;
+            val[i] = (i * THREADS < n && slot < n) ? vals0[lo + slot] : 0u;
+        }
+        // all list entries are on their way before the first dependent depth gather is issued
+        uint32_t kmin = ~0u, kmax = 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        k_or |= (uint32_t)__shfl_xor((int)k_or, o, 64);
-        k_and &= (uint32_t)__shfl_xor((int)k_and, o, 64);
-    }
-    if (lane == 0) { s_red[wave] = k_or; s_red[WAVES + wave] = k_and; }
-    __syncthreads();
-    uint32_t varying;
-    {
-        uint32_t o = 0u, a = ~0u;
-        for (int w = 0; w < WAVES; w++) { o |= s_red[w]; a &= s_red[WAVES + w]; }
-        varying = o ^ a;
-    }
-    for (int shift = 0; shift < 32; shift += 8) {
-        if (((varying >> shift) & 0xffu) == 0u) continue;  // digit constant over the segment (block-uniform)
-        uint32_t tot;
-        block_rank_pass<ITEMS, WAVES>(key, shift, n, quota, s_cnt, s_start, s_wtot, pos, tot);
+        for (int i = 0; i < SEG_ITEMS; i++) {
+            const int slot = i * THREADS + tid;
+            if (i * THREADS < n && slot < n) {
+                key[i] = __float_as_uint(depth[val[i]]);
+                kmin = min(kmin, key[i]);
+                kmax = max(kmax, key[i]);
+            } else {
+                key[i] = 0u;
+            }
+        }
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) {
-            const int slot = wave * quota + i * 64 + lane;
-            if (i * 64 < quota && slot < n) { s_key[pos[i]] = key[i]; s_val[pos[i]] = val[i]; }
+        for (int o = 32; o > 0; o >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+        }
+        if (lane == 0) { s_red[0][wave] = kmin; s_red[1][wave] = kmax; }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < WAVES; v++) { kmin = min(kmin, s_red[0][v]); kmax = max(kmax, s_red[1][v]); }
+        const uint32_t span = kmax - kmin;
+        if (span == 0u) continue;  // one depth for the whole list: the incoming order is the answer
+        int sh = 32 - __clz((int)span);  // bit length of the span
+        sh = max(0, sh - (THREADS == 256 ? 11 : 12));  // span >> sh < NB
+        static_assert(THREADS == 256 || THREADS == 512, "NB = 8 THREADS is 2^11 or 2^12");
+
+#pragma unroll
+        for (int i = 0; i < SEG_ITEMS; i++) {
+            const int slot = i * THREADS + tid;
+            if (i * THREADS < n && slot < n) atomicAdd(&s_cnt[(key[i] - kmin) >> sh], 1u);
+        }
+        __syncthreads();
+        bool too_full;
+        {   // exclusive scan over the buckets (thread t: buckets 8t .. 8t+7), and the largest bucket
+            uint32_t c[8], sum = 0, big = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { c[j] = s_cnt[8 * tid + j]; sum += c[j]; big = max(big, c[j]); }
+            const uint32_t incl = wave_incl_scan_u32(sum, lane);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, o, 64));
+            if (lane == 63) s_red[0][wave] = incl;
+            if (lane == 0) s_red[2][wave] = big;
+            __syncthreads();
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int v = 0; v < WAVES; v++) {
+                if (v < wave) run += s_red[0][v];
+                big = max(big, s_red[2][v]);
+            }
+            too_full = big > SEG_BUCKET_LIMIT;
+            if (!too_full) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) { s_cnt[8 * tid + j] = run; run += c[j]; }
+            }
+        }
+        if (too_full) {
+            if (tid == 0) hard[4 + (size_t)out * T + atomicAdd(&hard[out], 1u)] = tile;
+            continue;
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) {
-            const int slot = wave * quota + i * 64 + lane;
-            if (i * 64 < quota && slot < n) { key[i] = s_key[slot]; val[i] = s_val[slot]; }
+        for (int i = 0; i < SEG_ITEMS; i++) {
+            const int slot = i * THREADS + tid;
+            if (i * THREADS < n && slot < n) {
+                const uint32_t p = atomicAdd(&s_cnt[(key[i] - kmin) >> sh], 1u);
+                s_key[p] = key[i];
+                s_slot[p] = (uint16_t)slot;
+            }
         }
         __syncthreads();
-    }
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const int slot = wave * quota + i * 64 + lane;
-        if (i * 64 < quota && slot < n) vals0[lo + slot] = val[i];
+        for (int i = 0; i < SEG_ITEMS; i++) {
+            const int slot = i * THREADS + tid;
+            if (i * THREADS < n && slot < n) {
+                const uint32_t b = (key[i] - kmin) >> sh;
+                const uint32_t begin = b ? s_cnt[b - 1] : 0u, end = s_cnt[b];
+                uint32_t r = begin;
+                for (uint32_t e = begin; e < end; e++) {
+                    const uint32_t k = s_key[e];
+                    r += (k < key[i] || (k == key[i] && s_slot[e] < (uint16_t)slot)) ? 1u : 0u;
+                }
+                vals0[lo + r] = val[i];
+            }
+        }
     }
 }
 
-// Segments longer than STILE pairs: the same four passes, chunk by chunk, ping-ponging through the spare buffers
-// (depth keys in keys0 / keys1, the list in vals0 / vals1; four passes end where they started, in vals0).
-__global__ __launch_bounds__(ST) void segment_sort_long_kernel(const uint2* __restrict__ ranges,
+// The general per-tile sort: four stable 8-bit passes over the depth bits, chunk by chunk, ping-ponging through the
+// spare buffers (depth bits in keys0 / keys1, the list in vals0 / vals1; four passes end where they started, in
+// vals0).  Any list length, any distribution of depths; workgroups share out the tiles of work list `in`.
+__global__ __launch_bounds__(ST) void segment_sort_long_kernel(int T, const uint2* __restrict__ ranges,
                                                                const float* __restrict__ depth, uint32_t* keys0,
-                                                               uint32_t* vals0, uint32_t* keys1, uint32_t* vals1)
+                                                               uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
+                                                               const uint32_t* __restrict__ hard, int in)
 {
     __shared__ uint32_t s_cnt[SWAVES][256];
     __shared__ uint32_t s_start[256];
     __shared__ uint32_t s_base[256];
     __shared__ uint32_t s_wtot[SWAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint2 range = ranges[blockIdx.x];
-    const int n = (int)(range.y - range.x);
-    if (n <= STILE) return;  // block-uniform
-    const size_t lo = range.x;
-    const int quota = 64 * SI;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = pass * 8;
-        const uint32_t* ksrc = (pass & 1) ? keys1 : keys0;
-        const uint32_t* vsrc = (pass & 1) ? vals1 : vals0;
-        uint32_t* kdst = (pass & 1) ? keys0 : keys1;
-        uint32_t* vdst = (pass & 1) ? vals0 : vals1;
-        __syncthreads();  // the previous pass's stores are visible to the whole workgroup
-        // digit histogram of the whole segment -> running digit bases
-        s_cnt[0][tid] = 0;
-        __syncthreads();
-        // the first pass has no keys yet: it builds them from the depth of each listed Gaussian
-        for (int i = tid; i < n; i += ST) {
-            const uint32_t k = pass == 0 ? __float_as_uint(depth[vsrc[lo + i]]) : ksrc[lo + i];
-            atomicAdd(&s_cnt[0][(k >> shift) & 0xffu], 1u);
-        }
-        __syncthreads();
-        {
-            const uint32_t c = s_cnt[0][tid];
-            const uint32_t incl = wave_incl_scan_u32(c, lane);
-            if (lane == 63) s_wtot[wave] = incl;
+    const uint32_t n_work = hard[in];
+    for (uint32_t h = blockIdx.x; h < n_work; h += gridDim.x) {
+        const uint2 range = ranges[hard[4 + (size_t)in * T + h]];
+        const int n = (int)(range.y - range.x);
+        const size_t lo = range.x;
+        const int quota = 64 * SI;
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = pass * 8;
+            const uint32_t* ksrc = (pass & 1) ? keys1 : keys0;
+            const uint32_t* vsrc = (pass & 1) ? vals1 : vals0;
+            uint32_t* kdst = (pass & 1) ? keys0 : keys1;
+            uint32_t* vdst = (pass & 1) ? vals0 : vals1;
+            __syncthreads();  // the previous pass's stores are visible to the whole workgroup
+            // digit histogram of the whole segment -> running digit bases
+            s_cnt[0][tid] = 0;
             __syncthreads();
-            uint32_t b = 0;
-            for (int w = 0; w < wave; w++) b += s_wtot[w];
-            s_base[tid] = b + incl - c;
-        }
-        __syncthreads();
-        for (int c0 = 0; c0 < n; c0 += STILE) {
-            const int m = min(STILE, n - c0);
-            uint32_t key[SI], pos[SI], val[SI];
-#pragma unroll
-            for (int i = 0; i < SI; i++) {
-                const int slot = wave * quota + i * 64 + lane;
-                const bool valid = slot < m;
-                val[i] = valid ? vsrc[lo + c0 + slot] : 0u;
-                key[i] = !valid ? ~0u : pass == 0 ? __float_as_uint(depth[val[i]]) : ksrc[lo + c0 + slot];
+            // the first pass has no keys yet: it builds them from the depth of each listed Gaussian
+            for (int i = tid; i < n; i += ST) {
+                const uint32_t k = pass == 0 ? __float_as_uint(depth[vsrc[lo + i]]) : ksrc[lo + i];
+                atomicAdd(&s_cnt[0][(k >> shift) & 0xffu], 1u);
             }
-            uint32_t tot;
-            block_rank_pass<SI>(key, shift, m, quota, s_cnt, s_start, s_wtot, pos, tot);
-            // pos = rank inside the chunk ordered by digit; convert to the segment-wide position
+            __syncthreads();
+            {
+                const uint32_t c = s_cnt[0][tid];
+                const uint32_t incl = wave_incl_scan_u32(c, lane);
+                if (lane == 63) s_wtot[wave] = incl;
+                __syncthreads();
+                uint32_t b = 0;
+                for (int w = 0; w < wave; w++) b += s_wtot[w];
+                s_base[tid] = b + incl - c;
+            }
+            __syncthreads();
+            for (int c0 = 0; c0 < n; c0 += STILE) {
+                const int m = min(STILE, n - c0);
+                uint32_t key[SI], pos[SI], val[SI];
 #pragma unroll
-            for (int i = 0; i < SI; i++) {
-                const int slot = wave * quota + i * 64 + lane;
-                if (slot < m) {
-                    const uint32_t d = (key[i] >> shift) & 0xffu;
-                    const uint32_t g = s_base[d] + (pos[i] - s_start[d]);
-                    kdst[lo + g] = key[i];
-                    vdst[lo + g] = val[i];
+                for (int i = 0; i < SI; i++) {
+                    const int slot = wave * quota + i * 64 + lane;
+                    const bool valid = slot < m;
+                    val[i] = valid ? vsrc[lo + c0 + slot] : 0u;
+                    key[i] = !valid ? ~0u : pass == 0 ? __float_as_uint(depth[val[i]]) : ksrc[lo + c0 + slot];
                 }
+                uint32_t tot;
+                block_rank_pass<SI>(key, shift, m, quota, s_cnt, s_start, s_wtot, pos, tot);
+                // pos = rank inside the chunk ordered by digit; convert to the segment-wide position
+#pragma unroll
+                for (int i = 0; i < SI; i++) {
+                    const int slot = wave * quota + i * 64 + lane;
+                    if (slot < m) {
+                        const uint32_t d = (key[i] >> shift) & 0xffu;
+                        const uint32_t g = s_base[d] + (pos[i] - s_start[d]);
+                        kdst[lo + g] = key[i];
+                        vdst[lo + g] = val[i];
+                    }
+                }
+                __syncthreads();
+                s_base[tid] += tot;
+                __syncthreads();
             }
-            __syncthreads();
-            s_base[tid] += tot;
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
@@ -423,19 +486,16 @@ void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t cap
 }
 
 // The depth order obtained AFTER the tile-level sort instead of before it: one workgroup per tile fetches the depth
-// of each of its Gaussians (a gather from the per-Gaussian depth array), sorts its segment by the 32 depth bits,
-// stably, entirely in registers + LDS (four 8-bit passes, passes whose digit is constant over the segment are
-// skipped) and writes the list back in place; segments longer than 4096 pairs run the same passes ping-ponging
-// through global memory.  Its cost grows with the number of INSTANCES (and steeply once lists outgrow a workgroup),
-// the Gaussian-level sort's with the number of Gaussians: the forward pass picks whichever is cheaper for the call.
+// of each of its Gaussians (a gather from the per-Gaussian depth array) and sorts its list by the 32 depth bits,
+// stably, in LDS (segment_sort_bucket_kernel).  What that kernel cannot take (more than 4096 entries, or depths
+// crowding into one bucket) goes to the general kernel, a small grid that finds its tiles in a work list and costs a
+// few microseconds when the list is empty.  The cost of this route grows with the number of INSTANCES (and steeply
+// once lists outgrow a workgroup), the Gaussian-level sort's with the number of Gaussians: the forward pass picks
+// whichever is cheaper for the call.
 void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
-                              uint32_t* const vals[2])
+                              uint32_t* const vals[2], uint32_t* hard)
 {
-    // every tile with two or more entries is claimed by exactly one of the three launches (by segment length); the
-    // others exit at once
-    hipLaunchKernelGGL((segment_sort_small_kernel<8, ST>), dim3(T), dim3(ST), 0, s, ranges, 0, depth, vals[0]);
-    hipLaunchKernelGGL((segment_sort_small_kernel<8, 2 * ST>), dim3(T), dim3(2 * ST), 0, s, ranges, ST * 8, depth,
-                       vals[0]);
-    hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T), dim3(ST), 0, s, ranges, depth, keys[0], vals[0], keys[1],
-                       vals[1]);
+    hipLaunchKernelGGL(segment_sort_bucket_kernel<ST>, dim3(T), dim3(ST), 0, s, T, ranges, depth, vals[0], hard, -1, 0);
+    hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T < 512 ? T : 512), dim3(ST), 0, s, T, ranges, depth, keys[0],
+                       vals[0], keys[1], vals[1], hard, 0);
 }

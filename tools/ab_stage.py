@@ -23,6 +23,7 @@ def child(args):
     from neuralgaussiansplatting_amd import synthetic, view_parallel
     from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C
     dev = torch.device("cuda:0")
+    _C.lib().ngs_debug_depth_order({"auto": -1, "tile": 0, "gaussian": 1}[args.depth_order])
     P, W, H, D, M, ls, ext = synthetic.CONFIGS[args.config]
     if args.log_scale is not None:
         ls = tuple(args.log_scale)
@@ -71,6 +72,9 @@ def main():
     ap.add_argument("--view", type=int, default=0)
     ap.add_argument("--log-scale", type=float, nargs=2, default=None)
     ap.add_argument("--dump", default=None)
+    ap.add_argument("--depth-order", default="auto", choices=("auto", "tile", "gaussian"),
+                    help="where the depth order comes from: the library's choice, the per-tile sort, or the sort of "
+                         "the Gaussians")
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -83,7 +87,8 @@ def main():
             env["NGS_RASTERIZER_LIB"] = os.path.abspath(lib)
         dump = "/tmp/ab_dump_%d.pt" % i
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--config", args.config, "--steps", str(args.steps),
-               "--warmup", str(args.warmup), "--view", str(args.view), "--dump", dump]
+               "--warmup", str(args.warmup), "--view", str(args.view), "--dump", dump, "--depth-order",
+               args.depth_order]
         if args.log_scale is not None:
             cmd += ["--log-scale", str(args.log_scale[0]), str(args.log_scale[1])]
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
