@@ -354,12 +354,12 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     // are emitted -- 14 small launches whose cost follows P -- or a sort of every tile's list afterwards -- two
     // launches whose cost follows the instance count and rises steeply once lists outgrow a workgroup (4096
     // entries).  Measured on MI355X the first costs about 90 us + 48 us per million Gaussians, the second about
-    // 12 us + 10.5 us per million instances while lists are short (0.13 ms at 1500 per tile and 12 M instances,
-    // 0.19 ms at 2000 and 16.5 M, 0.53 ms at 2900 and 24 M, where the first lists pass 4096 entries).
+    // 12 us + 10.5 us per million instances while no list passes 4096 entries (0.13 ms at 1500 per tile on average
+    // and 12 M instances, 0.19 ms at 2000 and 16.5 M; 0.53 ms at 2900 and 24 M, where the longest lists do).
     bool depth_first;
     {
         const double inst = (double)capacity, per_tile = inst / (double)T;
-        const double by_tile = 12.0 + 10.5e-6 * inst * (per_tile > 2000.0 ? 1.0 + (per_tile - 2000.0) / 700.0 : 1.0);
+        const double by_tile = 12.0 + 10.5e-6 * inst * (per_tile > 2600.0 ? 1.0 + (per_tile - 2600.0) / 300.0 : 1.0);
         const double by_gaussian = 90.0 + 48e-6 * (double)P;
         depth_first = by_gaussian < by_tile;
         if (g_depth_order_choice >= 0) depth_first = g_depth_order_choice != 0;

@@ -23,6 +23,13 @@ view instead of 3M), the other 11 floats go through a small all-reduce, and ever
 rank rebuilds the summed SH gradient locally, adding the views in rank order.
 On 8 GPUs at M = 16 that moves about 2.6x fewer bytes per GPU than the dense
 all-reduce, and all ranks hold bit-identical SH gradients.
+
+Both forms take ``views_per_rank``: a rank then renders that many views per
+step, every view's collectives are queued as soon as its backward pass is
+(``post_view``) and travel while the next view is rendered, and ``finish``
+waits once and adds the views up.  With ``stats`` the two sums of the
+densification statistics (scene/gaussian_model.py:550-552) ride in the same
+buffers, so after a step every rank holds their totals over all views.
 """
 import torch
 import torch.distributed as dist

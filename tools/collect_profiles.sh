@@ -14,6 +14,14 @@ done
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29671 \
     bench.py --gpus 2 --steps 5 --warmup 1 --backend gloo --no-idxmap 2> $OUT/gloo2.err | grep '"metric"' > $OUT/c4_gloo2_rehearsal.json
 echo "gloo rehearsal done"
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29673 \
+    bench.py --gpus 2 --steps 5 --warmup 1 --backend gloo --no-idxmap --views-per-gpu 2 2> $OUT/gloo2v2.err | grep '"metric"' > $OUT/c4_gloo2_views2_rehearsal.json
+echo "gloo rehearsal with two views per rank done"
+timeout -k 10 300 python3 bench.py --no-idxmap --no-cpu-baseline --unfused-train > $OUT/c4_bench_unfused_train.json 2> $OUT/c4_unfused.err
+timeout -k 10 300 python3 bench.py --no-idxmap --no-cpu-baseline --views-per-gpu 2 > $OUT/c4_bench_views2.json 2> $OUT/c4_views2.err
+echo "training variants done"
+timeout -k 10 600 python3 tools/footprint_sweep.py $OUT/c4_footprint.json > $OUT/footprint.log 2>&1
+echo "footprint sweep done"
 timeout -k 10 300 python3 tools/train_demo.py --iterations 7000 --gt 150000 --init 30000 --views 100 --out $OUT/train_demo.json > /dev/null 2> $OUT/train_demo.err
 echo "training run done"
 cd /tmp

@@ -7,9 +7,12 @@ SRC=gpurun_out/final
 for c in c1 c2 c3 c4 c5; do cp $SRC/${c}_bench.json profiles/${TAG}_${c}_bench.json; done
 cp $SRC/c4_gloo2_rehearsal.json profiles/${TAG}_c4_gloo2_rehearsal.json
 cp $SRC/train_demo.json profiles/${TAG}_train_demo.json
+for f in c4_gloo2_views2_rehearsal c4_bench_unfused_train c4_bench_views2 c4_footprint; do
+    if [ -f $SRC/$f.json ]; then cp $SRC/$f.json profiles/${TAG}_$f.json; fi
+done
 cp $SRC/trace/*/*_kernel_stats.csv profiles/${TAG}_c4_final_kernel_stats.csv
 python3 tools/kernel_stats_md.py profiles/${TAG}_c4_final_kernel_stats.csv "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline" > profiles/${TAG}_c4_final_kernel_stats.md
-python3 tools/pmc_summary.py --fetch $SRC/pmc_fetch --write $SRC/pmc_write --config c4 --fwd-runs 5 --bwd-runs 4 \
+python3 tools/pmc_summary.py --fetch $SRC/pmc_fetch --write $SRC/pmc_write --config c4 \
     --out profiles/hbm_traffic.json --raw profiles/${TAG}_c4_pmc_traffic.json
 python3 tools/pmc_valu_summary.py $SRC/pmc_valu profiles/valu_issue.json c4 profiles/${TAG}_c4_valu.md > profiles/${TAG}_c4_valu.md
 python3 tools/results_tables.py $TAG

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc passes into per-kernel HBM traffic per launch.
 
     python tools/pmc_summary.py --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write \\
-        --config c4 --fwd-runs 5 --bwd-runs 4 --out profiles/hbm_traffic.json --raw profiles/r01_c4_pmc_traffic.json
+        --config c4 --out profiles/hbm_traffic.json --raw profiles/r02_c4_pmc_traffic.json
 
 FETCH_SIZE and WRITE_SIZE are collected in separate passes (they do not fit the
 TCC counter slots together) and are reported by rocprofv3 in KiB.  On gfx950
@@ -25,7 +25,7 @@ STAGE_KERNELS = {
     "duplicate_with_keys": ["duplicate_kernel"],
     "radix_sort_tile_bits": ["sort_hist_kernel", "sort_scan_kernel", "sort_scatter_kernel"],
     "tile_ranges": ["tile_ranges_kernel"],
-    "segment_sort_depth": ["segment_sort_small_kernel", "segment_sort_long_kernel"],
+    "segment_sort_depth": ["segment_sort_bucket_kernel", "segment_sort_long_kernel"],
     "depth_sort_gaussians": ["depth_order_kernel"],  # its radix passes are counted under radix_sort_tile_bits
     "render_fwd": ["render_fwd_kernel"],
     "render_bwd": ["render_bwd_kernel"],
@@ -61,14 +61,17 @@ def main():
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
     ap.add_argument("--config", default="c4")
-    ap.add_argument("--fwd-runs", type=int, required=True, help="forward passes the profiled command ran "
-                    "(bench.py: warmup + steps + 1 for the statistics forward)")
-    ap.add_argument("--bwd-runs", type=int, required=True, help="backward passes it ran (bench.py: warmup + steps)")
+    ap.add_argument("--fwd-runs", type=int, default=0, help="forward passes the profiled command ran (default: the "
+                    "number of render_fwd_kernel launches in the fetch pass)")
+    ap.add_argument("--bwd-runs", type=int, default=0, help="backward passes it ran (default: render_bwd_kernel "
+                    "launches)")
     ap.add_argument("--out", required=True)
     ap.add_argument("--raw", required=True)
     a = ap.parse_args()
     rd = per_kernel(a.fetch, "FETCH_SIZE")
     wr = per_kernel(a.write, "WRITE_SIZE")
+    a.fwd_runs = a.fwd_runs or rd["render_fwd_kernel"][1]
+    a.bwd_runs = a.bwd_runs or rd["render_bwd_kernel"][1]
     raw = {}
     for k in sorted(set(rd) | set(wr)):
         r, rn = rd.get(k, (0.0, 0))

@@ -33,6 +33,8 @@ def main():
     print("| stage | ms | algorithmic GB | GB/s | PMC HBM bytes (read×2 + write) |")
     print("|---|---|---|---|---|")
     for key, label in STAGES:
+        if key not in d["stages"]:  # a stage of the depth-order route this run did not take
+            continue
         v = d["stages"][key]
         t = traffic.get(key)
         tiny = v["algorithmic_GB"] <= 0.001
