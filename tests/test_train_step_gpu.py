@@ -894,3 +894,78 @@ def test_fused_optimiser_step_is_bit_exact_given_the_same_gradients(C):
     assert not torch.equal(a.xyz, sc.means3D.to(DEV))
     assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and float(a.xyz_gradient_accum.sum()) > 0
     assert torch.equal(a.denom, b.denom) and torch.equal(a.max_radii2D, b.max_radii2D)
+
+
+def test_view_statistics_rows(C):
+    """ngs_view_statistics: the increments of xyz_gradient_accum / denom (scene/gaussian_model.py:550-552) as two
+    summable rows, zeros where nothing was rendered, and the running maximum of the radii (train.py:115)."""
+    g = torch.Generator().manual_seed(4)
+    for P in (1, 63, 1000, 4097):
+        g2d = torch.randn(P, 3, generator=g).to(DEV)
+        radii = torch.randint(-1, 30, (P,), generator=g, dtype=torch.int32).to(DEV)
+        big = torch.randint(0, 25, (P,), generator=g, dtype=torch.int32).to(DEV)
+        norm, vis = torch.full((P,), 7.0, device=DEV), torch.full((P,), 7.0, device=DEV)
+        want_big = torch.where(radii > 0, torch.maximum(big, radii), big)
+        C.view_statistics(g2d, radii, norm, vis, big)
+        seen = radii > 0
+        assert torch.equal(vis, seen.float())
+        want = torch.where(seen, torch.sqrt(g2d[:, 0] * g2d[:, 0] + g2d[:, 1] * g2d[:, 1]), torch.zeros((), device=DEV))
+        assert torch.allclose(norm, want, rtol=1e-6, atol=0)
+        assert float(norm[~seen].abs().sum()) == 0.0
+        assert torch.equal(big, want_big)
+        C.view_statistics(g2d, radii, norm, vis)  # without the maximum
+    with pytest.raises(RuntimeError):
+        C.view_statistics(g2d, radii.long(), norm, vis)
+
+
+def test_raw_and_fused_entry_points_reject_bad_arguments(C):
+    """Error paths of the raw-parameter entry points through the C ABI: every one returns an error (-> RuntimeError)
+    instead of launching."""
+    import ctypes
+    sc, raw, W, H = _raw_scene("small")
+    P = sc.means3D.shape[0]
+    cam = make_camera(W, H, synthetic.FOVX, (0.7, 0.5, -4.0), device=DEV)
+    tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    bg, e = torch.zeros(3, device=DEV), torch.empty(0)
+    view = (cam.world_view_transform, cam.full_proj_transform, tanx, tany)
+    with pytest.raises(RuntimeError, match="scales"):
+        C.rasterize_gaussians_raw(bg, sc.means3D, e, raw["opacity"], e, raw["rotation"], 1.0, *view, H, W, sc.shs, 3,
+                                  cam.camera_center, False, False)
+    r = C.rasterize_gaussians_raw(bg, sc.means3D, e, raw["opacity"], raw["scaling"], raw["rotation"], 1.0, *view, H, W,
+                                  sc.shs, 3, cam.camera_center, False, False)
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(DEV)
+    with pytest.raises(RuntimeError, match="raw"):
+        C.rasterize_gaussians_backward_raw(bg, sc.means3D, r[2], e, e, raw["scaling"], raw["rotation"], 1.0, *view, dL,
+                                           sc.shs, 3, cam.camera_center, r[3], r[0], r[4], r[5], False)
+    z = lambda t: torch.zeros_like(t)
+    params = dict(xyz=sc.means3D.clone(), features=sc.shs.clone(), opacity=raw["opacity"].clone(),
+                  scaling=raw["scaling"].clone(), rotation=raw["rotation"].clone())
+    groups = {k: (p, z(p), z(p), 1e-3, 1) for k, p in params.items()}
+    call = lambda grp, **kw: C.rasterize_gaussians_backward_train(
+        bg, r[2], 1.0, *view, dL, 3, cam.camera_center, r[3], r[0], r[4], r[5], grp, 1e-4, **kw)
+    bad = dict(groups)
+    bad["xyz"] = groups["xyz"][:4] + (0,)  # step 0
+    with pytest.raises(RuntimeError, match="step"):
+        call(bad)
+    bad = dict(groups)
+    bad["scaling"] = (params["scaling"], z(params["scaling"])[:-1], z(params["scaling"]), 1e-3, 1)
+    with pytest.raises(RuntimeError, match="scaling"):
+        call(bad)
+    with pytest.raises(RuntimeError, match="Adam"):
+        call(groups, betas=(1.0, 0.999))
+    L = C.lib()
+    st = C._TrainState()
+    assert L.ngs_rasterize_backward_train(P, 3, r[0], None, W, H, ctypes.c_float(1.0), None, None, None,
+                                          ctypes.c_float(tanx), ctypes.c_float(tany), None, None, None, None, None,
+                                          ctypes.byref(st), 0, None) != 0
+    assert b"missing" in L.ngs_last_error()
+    assert L.ngs_rasterize_backward_train(P, 3, r[0], None, W, H, ctypes.c_float(1.0), None, None, None,
+                                          ctypes.c_float(tanx), ctypes.c_float(tany), None, None, None, None, None, None,
+                                          0, None) != 0
+    # nothing moved
+    assert torch.equal(params["xyz"], sc.means3D) and torch.equal(params["opacity"], raw["opacity"])
+    # and a good call does move everything
+    call(groups, densify=(torch.zeros(P, 1, device=DEV), torch.zeros(P, 1, device=DEV),
+                          torch.zeros(P, dtype=torch.int32, device=DEV)))
+    torch.cuda.synchronize()
+    assert not torch.equal(params["xyz"], sc.means3D) and not torch.equal(params["features"], sc.shs)
