@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 from neuralgaussiansplatting_amd import build_id, synthetic, view_parallel  # noqa: E402
 from neuralgaussiansplatting_amd.debug_state import decode_state  # noqa: E402
-from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C  # noqa: E402
+from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _lib as _C  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 

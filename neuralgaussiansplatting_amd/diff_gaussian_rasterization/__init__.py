@@ -13,6 +13,7 @@ from typing import NamedTuple
 import torch
 import torch.nn as nn
 
+from . import _lib  # noqa: F401  (binds the compiled extension to the library)
 from . import _C
 
 

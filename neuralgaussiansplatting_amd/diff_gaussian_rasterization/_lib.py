@@ -1,10 +1,12 @@
-"""Binding layer between torch tensors and ``libngs_rasterizer.so``.
+"""Python bindings of ``libngs_rasterizer.so`` beyond the reference's three.
 
-Plays the role of the reference's compiled ``_C`` module (pybind names at
-submodules/diff-gaussian-rasterization/ext.cpp:15-19, marshalling at
-rasterize_points.cu:35-217): the three functions below keep its names,
-argument order and return tuples.  The product path is the HIP library; there
-is no CPU fallback, and a missing library or a non-GPU tensor is an error.
+The reference's compiled ``_C`` module (pybind names at submodules/diff-gaussian-rasterization/ext.cpp:15-19,
+marshalling at rasterize_points.cu:35-217) is a compiled torch extension here as well: ``_C`` next to this file,
+built from csrc/torch_ext.cpp, with the same three functions, argument orders and return tuples.  This module binds
+that extension to the library (``_C.bind``) and re-exports its three functions unchanged; everything else the
+library offers -- the backward pass writing into caller-provided buffers or fused with optimiser steps, the
+raw-parameter entry points, loss, Adam, multi-view helpers, stage timers -- is bound here through ctypes.  The
+product path is the HIP library; there is no CPU fallback, and a missing library or a non-GPU tensor is an error.
 """
 import ctypes
 import os
@@ -18,6 +20,19 @@ NUM_CHANNELS = 3  # cuda_rasterizer/config.h:15
 
 _ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 _lib = None
+
+try:
+    from . import _C  # the compiled torch extension (csrc/torch_ext.cpp)
+except ImportError as _err:  # pragma: no cover - a build problem, reported where it is needed
+    raise ImportError("the compiled binding diff_gaussian_rasterization/_C is not built; run `python -c 'import "
+                      "__graft_entry__ as g; g.build()'` or `make -C neuralgaussiansplatting_amd/csrc`") from _err
+if os.path.exists(LIB_PATH):
+    _C.bind(LIB_PATH)  # without the library the three functions raise "has not been bound"
+
+# The reference's three entry points, straight from the compiled extension: no Python runs inside a call.
+rasterize_gaussians = _C.rasterize_gaussians
+rasterize_gaussians_backward = _C.rasterize_gaussians_backward
+mark_visible = _C.mark_visible
 
 
 def lib():
@@ -108,21 +123,19 @@ class _Growable:
 # its own count.  A call whose count exceeds the estimate repeats the stages after the count inside the library.
 _instance_hint = {}
 # Tests and experiments: an int here replaces the estimate (0 = wait for the count before sizing the buffer, as the
-# reference does); None = use the estimate.
+# reference does); None = use the estimate.  Set through set_forced_binning_capacity, which tells the compiled
+# extension as well.
 forced_binning_capacity = None
+
+
+def set_forced_binning_capacity(capacity):
+    global forced_binning_capacity
+    forced_binning_capacity = capacity
+    _C.set_forced_binning_capacity(-1 if capacity is None else int(capacity))
 
 
 def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-
-
-def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
-                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
-    """-> (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)"""
-    return _forward(False, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
-                    viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                    prefiltered, debug)
 
 
 def rasterize_gaussians_raw(background, means3D, colors, opacity_raw, scales_raw, rotations_raw, scale_modifier,
@@ -130,14 +143,14 @@ def rasterize_gaussians_raw(background, means3D, colors, opacity_raw, scales_raw
                             prefiltered, debug):
     """``rasterize_gaussians`` on the optimiser's raw parameters: sigmoid / exp / normalize
     (scene/gaussian_model.py:36-43) are applied inside the library.  Same return tuple."""
-    return _forward(True, background, means3D, colors, opacity_raw, scales_raw, rotations_raw, scale_modifier,
+    return _forward_raw(background, means3D, colors, opacity_raw, scales_raw, rotations_raw, scale_modifier,
                     torch.empty(0), viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
                     campos, prefiltered, debug)
 
 
-def _forward(raw, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
-             viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-             prefiltered, debug):
+def _forward_raw(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                 viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                 prefiltered, debug):
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D)
@@ -167,10 +180,7 @@ def _forward(raw, background, means3D, colors, opacity, scales, rotations, scale
                 int(bool(prefiltered)), _ptr(out_color), _ptr(radii), int(bool(debug)), _stream(dev),
                 ctypes.byref(rendered), ctypes.c_longlong(capacity))
         with torch.cuda.device(dev):
-            if raw:
-                _check(lib().ngs_rasterize_forward_raw(*head, *tail))
-            else:
-                _check(lib().ngs_rasterize_forward_presized(*head, _ptr(cov3D_precomp), *tail))
+            _check(lib().ngs_rasterize_forward_raw(*head, *tail))
         if len(_instance_hint) > 256:
             _instance_hint.clear()
         _instance_hint[hint_key] = (P, rendered.value)
@@ -183,11 +193,13 @@ def _forward(raw, background, means3D, colors, opacity, scales, rotations, scale
 _READY_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 
 
-def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
-                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 return_conic=False, out=None, skip_sh=False, sh_adam=None, early_color=None):
-    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+def rasterize_gaussians_backward_ex(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                    cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
+                                    degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
+                                    return_conic=False, out=None, skip_sh=False, sh_adam=None, early_color=None):
+    """``rasterize_gaussians_backward`` with what a trainer or a multi-view exchange needs on top of the reference's
+    argument list.
+    -> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     (rasterize_points.cu:195); with ``return_conic`` a ninth element dL_dconic [P,2,2] is appended.
     ``out`` may map any of those names to a preallocated contiguous float32 tensor of the right size (for
     instance a slice of one flat gradient bucket that is all-reduced afterwards); the rest are allocated here.
@@ -572,20 +584,6 @@ def profile_read(reset=True):
     L.ngs_profile_read(ms, cnt, int(bool(reset)))
     L.ngs_profile_stage_name.restype = ctypes.c_char_p
     return {L.ngs_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}
-
-
-def mark_visible(means3D, viewmatrix, projmatrix):
-    """-> bool[P] (rasterize_points.cu:198-217)"""
-    _require_gpu(means3D)
-    dev = means3D.device
-    P = means3D.size(0)
-    present = torch.zeros((P,), dtype=torch.bool, device=dev)
-    if P != 0:
-        means3D, viewmatrix, projmatrix = (_f32(x, dev) for x in (means3D, viewmatrix, projmatrix))
-        with torch.cuda.device(dev):
-            _check(lib().ngs_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), _ptr(present),
-                                          _stream(dev)))
-    return present
 
 
 def state_layout(P, R, W, H):

@@ -5,7 +5,7 @@ import ctypes
 
 import torch
 
-from ..diff_gaussian_rasterization._C import _check, _f32, _ptr, _require_gpu, _stream, lib
+from ..diff_gaussian_rasterization._lib import _check, _f32, _ptr, _require_gpu, _stream, lib
 
 NUM_CHANNELS = 3   # submodules/rasterizer2/cuda_rasterizer/config.h:2
 NUM_FEATURES = 64  # config.h:3

@@ -4,7 +4,7 @@ import ctypes
 
 import torch
 
-from ..diff_gaussian_rasterization._C import _check, _f32, _ptr, _stream, lib
+from ..diff_gaussian_rasterization._lib import _check, _f32, _ptr, _stream, lib
 
 _configured = False
 

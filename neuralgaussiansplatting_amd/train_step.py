@@ -25,7 +25,7 @@ import math
 import torch
 
 from . import view_parallel
-from .diff_gaussian_rasterization import _C
+from .diff_gaussian_rasterization import _lib as _C
 
 
 class OptimizationParams:

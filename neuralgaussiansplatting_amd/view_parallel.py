@@ -34,7 +34,7 @@ buffers, so after a step every rank holds their totals over all views.
 import torch
 import torch.distributed as dist
 
-from .diff_gaussian_rasterization import _C
+from .diff_gaussian_rasterization import _lib as _C
 
 BUCKET_FIELDS = ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations")
 # densification statistics in summable form (see ``_C.view_statistics``): they ride in the gradients' all-reduce
@@ -199,7 +199,7 @@ class FactoredGradientExchange:
 
     def begin_view(self, cam, slot=0):
         """Called before the backward pass of this rank's view ``slot``: stores the camera position in the row that
-        will be gathered and returns the ``early_color`` argument of ``_C.rasterize_gaussians_backward``."""
+        will be gathered and returns the ``early_color`` argument of ``_C.rasterize_gaussians_backward_ex``."""
         P = self.P
         self.local[slot, 3 * P:3 * P + 3].copy_(cam.camera_center.reshape(3))
         if not self._on_gpu:
@@ -317,7 +317,7 @@ def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale
     parameter gradients landing in ``bucket.slot_views(slot)`` (either exchange form;
     ``bucket.post_view(slot, scene, cam, aux)`` then queues their exchange and ``bucket.finish(scene)`` completes
     the step; ``bucket.reduce(scene, cam, aux)`` does both for one view per rank).  ``sh_adam`` (see
-    ``_C.rasterize_gaussians_backward``) makes the backward pass apply the SH coefficients' optimiser step itself;
+    ``_C.rasterize_gaussians_backward_ex``) makes the backward pass apply the SH coefficients' optimiser step itself;
     single-rank single-view steps only.  A bucket built with ``stats`` also receives the view's densification
     statistics (and ``max_radii2D`` its running maximum).  Returns (color, radii, aux)."""
     e = torch.empty(0)
@@ -329,7 +329,7 @@ def forward_backward(scene, cam, bg, dL_dpix_fn, bucket, tanfovx, tanfovy, scale
     dL_dpix = dL_dpix_fn(color)
     early = bucket.begin_view(cam, slot) if sh_adam is None and hasattr(bucket, "begin_view") else None
     out = {k: v for k, v in bucket.slot_views(slot).items() if k not in STAT_FIELDS}
-    res = _C.rasterize_gaussians_backward(
+    res = _C.rasterize_gaussians_backward_ex(
         bg, scene.means3D, radii, e, scene.scales, scene.rotations, scale_modifier, e, cam.world_view_transform,
         cam.full_proj_transform, tanfovx, tanfovy, dL_dpix, scene.shs, scene.sh_degree, cam.camera_center, geom, R,
         binning, img, debug, out=out, skip_sh=bucket.skip_sh, sh_adam=sh_adam, early_color=early)

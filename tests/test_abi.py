@@ -24,7 +24,7 @@ def test_header_declares_the_three_reference_entry_points():
 
 
 def test_library_exports_every_declared_symbol():
-    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _lib as _C
     lib = _C.lib()
     for name in declared_symbols():
         assert hasattr(lib, name), name
@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_size_queries_and_layout_need_no_gpu():
-    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _lib as _C
     lib = _C.lib()
     g1, g2 = lib.ngs_required_geometry_bytes(1000), lib.ngs_required_geometry_bytes(2000)
     assert 0 < g1 < g2

@@ -1,6 +1,7 @@
 """Host-side behaviour of the drop-in package that needs no GPU: public
 surface, argument validation (reference __init__.py:187-195), error paths."""
 import inspect
+import re
 
 import pytest
 import torch
@@ -30,10 +31,22 @@ def test_public_surface_matches_reference_names_and_order():
     assert issubclass(dgr._RasterizeGaussians, torch.autograd.Function)
     for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"):
         assert callable(getattr(dgr._C, name))
-    assert list(inspect.signature(dgr._C.rasterize_gaussians).parameters) == [
+    # _C is a compiled extension like the reference's (ext.cpp:15-19); pybind11 records the argument names of
+    # rasterize_points.h:18-67 in the first line of each docstring
+    def names(fn):
+        head = fn.__doc__.splitlines()[0]
+        return re.findall(r"(\w+): ", head[head.index("("):head.rindex(") ->")])
+    assert type(dgr._C.rasterize_gaussians).__name__ == "builtin_function_or_method"
+    assert dgr._lib.rasterize_gaussians is dgr._C.rasterize_gaussians  # re-exported, not wrapped
+    assert names(dgr._C.rasterize_gaussians) == [
         "background", "means3D", "colors", "opacity", "scales", "rotations", "scale_modifier", "cov3D_precomp",
         "viewmatrix", "projmatrix", "tan_fovx", "tan_fovy", "image_height", "image_width", "sh", "degree", "campos",
         "prefiltered", "debug"]
+    assert names(dgr._C.rasterize_gaussians_backward) == [
+        "background", "means3D", "radii", "colors", "scales", "rotations", "scale_modifier", "cov3D_precomp",
+        "viewmatrix", "projmatrix", "tan_fovx", "tan_fovy", "dL_dout_color", "sh", "degree", "campos", "geomBuffer", "R",
+        "binningBuffer", "imageBuffer", "debug"]
+    assert names(dgr._C.mark_visible) == ["means3D", "viewmatrix", "projmatrix"]
 
 
 def test_exactly_one_colour_source():
@@ -65,16 +78,16 @@ def test_cpu_tensors_are_refused_not_silently_computed():
     with pytest.raises(RuntimeError, match="GPU only"):
         r.markVisible(m)
     with pytest.raises(RuntimeError, match="means3D must have dimensions"):
-        dgr._C.rasterize_gaussians(torch.zeros(3), torch.zeros(4, 2), *([torch.empty(0)] * 4), 1.0, torch.empty(0),
+        dgr._lib.rasterize_gaussians(torch.zeros(3), torch.zeros(4, 2), *([torch.empty(0)] * 4), 1.0, torch.empty(0),
                                    torch.eye(4), torch.eye(4), 0.3, 0.3, 16, 16, torch.empty(0), 0, torch.zeros(3),
                                    False, False)
 
 
 def test_missing_library_is_a_loud_error(monkeypatch):
-    monkeypatch.setattr(dgr._C, "_lib", None)
-    monkeypatch.setattr(dgr._C, "LIB_PATH", "/nonexistent/libngs_rasterizer.so")
+    monkeypatch.setattr(dgr._lib, "_lib", None)
+    monkeypatch.setattr(dgr._lib, "LIB_PATH", "/nonexistent/libngs_rasterizer.so")
     with pytest.raises(RuntimeError, match="not built"):
-        dgr._C.lib()
+        dgr._lib.lib()
 
 
 def test_gaussian_model_activations_and_covariance():

@@ -27,7 +27,7 @@ GRAD_REL_TO_MAX = 2e-4
 def dgr():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     from neuralgaussiansplatting_amd import diff_gaussian_rasterization as m
-    m._C.lib()  # fail loudly if the HIP library is missing
+    m._lib.lib()  # fail loudly if the HIP library is missing
     return m
 
 
@@ -35,7 +35,7 @@ def dgr():
 def depth_order(request, dgr):
     """Runs a test once per way of obtaining the depth order of the tile lists (a per-tile sort of the instances,
     or a sort of the Gaussians before their instances are emitted); left alone, the library picks one per call."""
-    L = dgr._C.lib()
+    L = dgr._lib.lib()
     L.ngs_debug_depth_order(0 if request.param == "by_tile" else 1)
     yield request.param
     L.ngs_debug_depth_order(-1)
@@ -52,22 +52,22 @@ def run_hip(dgr, c, dL_dpix=None, colors_precomp=None, cov3D_precomp=None, scale
             scale_modifier, e if cov3D_precomp is None else g(cov3D_precomp), g(cam.world_view_transform),
             g(cam.full_proj_transform), c["tanfovx"], c["tanfovy"], c["H"], c["W"],
             g(sc.shs) if colors_precomp is None else e, c["D"], g(cam.camera_center), prefiltered, debug)
-    dgr._C.forced_binning_capacity = binning_capacity
+    dgr._lib.set_forced_binning_capacity(binning_capacity)
     try:
-        R, color, radii, geom, binning, img = dgr._C.rasterize_gaussians(*args)
+        R, color, radii, geom, binning, img = dgr._lib.rasterize_gaussians(*args)
     finally:
-        dgr._C.forced_binning_capacity = None
+        dgr._lib.set_forced_binning_capacity(None)
     torch.cuda.synchronize()
     out = dict(R=R, color=color.cpu().numpy(), radii=radii.cpu().numpy(), binning_bytes=binning.numel())
     P = sc.means3D.shape[0]
     if P:
-        out.update(decode_state(dgr._C, P, R, c["W"], c["H"], geom, binning, img))
+        out.update(decode_state(dgr._lib, P, R, c["W"], c["H"], geom, binning, img))
     if dL_dpix is not None:
         bargs = (args[0], args[1], radii, args[2], args[4], args[5], scale_modifier, args[7], args[8], args[9],
                  c["tanfovx"], c["tanfovy"], g(dL_dpix), args[14], c["D"], args[16], geom, R, binning, img, debug)
         names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
                  "dL_drotations", "dL_dconic")
-        res = dgr._C.rasterize_gaussians_backward(*bargs, return_conic=True)
+        res = dgr._lib.rasterize_gaussians_backward_ex(*bargs, return_conic=True)
         torch.cuda.synchronize()
         out["grads"] = {n: t.cpu().numpy() for n, t in zip(names, res)}
     return out
@@ -218,12 +218,12 @@ def test_nonfinite_inputs_neither_hang_nor_fault(dgr):
     shs[15] = float("nan"); shs[16] = 1e30
     g = lambda t: t.to(dev)
     e = torch.empty(0)
-    R, color, radii, geom, binning, img = dgr._C.rasterize_gaussians(
+    R, color, radii, geom, binning, img = dgr._lib.rasterize_gaussians(
         g(c["bg"]), g(means), e, g(op), g(scales), g(rots), 1.0, e, g(cam.world_view_transform),
         g(cam.full_proj_transform), c["tanfovx"], c["tanfovy"], c["H"], c["W"], g(shs), 3, g(cam.camera_center), False,
         False)
     dL = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(1)).to(dev)
-    res = dgr._C.rasterize_gaussians_backward(
+    res = dgr._lib.rasterize_gaussians_backward(
         g(c["bg"]), g(means), radii, e, g(scales), g(rots), 1.0, e, g(cam.world_view_transform),
         g(cam.full_proj_transform), c["tanfovx"], c["tanfovy"], dL, g(shs), 3, g(cam.camera_center), geom, R, binning,
         img, False)
@@ -523,7 +523,7 @@ def test_empty_scene(dgr):
     e = torch.empty(0)
     z = torch.zeros(0, 3, device=dev)
     cam = case(P=1, W=32, H=16, D=0)["cam"]
-    R, color, radii, g, b, i = dgr._C.rasterize_gaussians(
+    R, color, radii, g, b, i = dgr._lib.rasterize_gaussians(
         torch.zeros(3, device=dev), z, e, torch.zeros(0, 1, device=dev), z, torch.zeros(0, 4, device=dev), 1.0, e,
         cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 0.3, 0.2, 16, 32,
         torch.zeros(0, 1, 3, device=dev), 0, cam.camera_center.to(dev), False, False)
@@ -535,7 +535,7 @@ def test_bad_means_shape_raises(dgr):
     dev = torch.device("cuda:0")
     e = torch.empty(0)
     with pytest.raises(RuntimeError, match="means3D must have dimensions"):
-        dgr._C.rasterize_gaussians(torch.zeros(3, device=dev), torch.zeros(4, 2, device=dev), e, e, e, e, 1.0, e,
+        dgr._lib.rasterize_gaussians(torch.zeros(3, device=dev), torch.zeros(4, 2, device=dev), e, e, e, e, 1.0, e,
                                    torch.eye(4, device=dev), torch.eye(4, device=dev), 0.3, 0.3, 16, 16, e, 0,
                                    torch.zeros(3, device=dev), False, False)
 
@@ -552,12 +552,12 @@ def test_backward_rejects_bad_degree_and_misaligned_quaternions(dgr):
     means, shs, scales, bg = g(sc.means3D), g(sc.shs), g(sc.scales), g(c["bg"])
     rots = g(sc.rotations)
     vm, pm, cp = g(cam.world_view_transform), g(cam.full_proj_transform), g(cam.camera_center)
-    R, color, radii, geom, binning, img = dgr._C.rasterize_gaussians(
+    R, color, radii, geom, binning, img = dgr._lib.rasterize_gaussians(
         bg, means, e, g(sc.opacities), scales, rots, 1.0, e, vm, pm, c["tanfovx"], c["tanfovy"], 32, 32, shs, 1, cp,
         False, False)
     dL = torch.randn(3, 32, 32, generator=torch.Generator().manual_seed(1)).to(dev)
     with pytest.raises(RuntimeError, match="SH degree"):
-        dgr._C.rasterize_gaussians_backward(bg, means, radii, e, scales, rots, 1.0, e, vm, pm, c["tanfovx"],
+        dgr._lib.rasterize_gaussians_backward(bg, means, radii, e, scales, rots, 1.0, e, vm, pm, c["tanfovx"],
                                             c["tanfovy"], dL, shs, 3, cp, geom, R, binning, img, False)
     # misaligned quaternions (a slice that starts 4 bytes into an allocation)
     flat = torch.zeros(4 * 50 + 1, device=dev)
@@ -565,15 +565,15 @@ def test_backward_rejects_bad_degree_and_misaligned_quaternions(dgr):
     shifted = flat[1:].view(50, 4)
     assert shifted.data_ptr() % 16 == 4
     with pytest.raises(RuntimeError, match="16-byte aligned"):
-        dgr._C.rasterize_gaussians_backward(bg, means, radii, e, scales, shifted, 1.0, e, vm, pm, c["tanfovx"],
+        dgr._lib.rasterize_gaussians_backward(bg, means, radii, e, scales, shifted, 1.0, e, vm, pm, c["tanfovx"],
                                             c["tanfovy"], dL, shs, 1, cp, geom, R, binning, img, False)
     out = torch.zeros(4 * 50 + 1, device=dev)
     with pytest.raises(RuntimeError, match="16-byte aligned"):
-        dgr._C.rasterize_gaussians_backward(bg, means, radii, e, scales, rots, 1.0, e, vm, pm, c["tanfovx"],
-                                            c["tanfovy"], dL, shs, 1, cp, geom, R, binning, img, False,
-                                            out={"dL_drotations": out[1:]})
+        dgr._lib.rasterize_gaussians_backward_ex(bg, means, radii, e, scales, rots, 1.0, e, vm, pm, c["tanfovx"],
+                                               c["tanfovy"], dL, shs, 1, cp, geom, R, binning, img, False,
+                                               out={"dL_drotations": out[1:]})
     # the forward pass takes misaligned quaternions (element loads) and gives the same image
-    R2, color2, *_ = dgr._C.rasterize_gaussians(
+    R2, color2, *_ = dgr._lib.rasterize_gaussians(
         bg, means, e, g(sc.opacities), scales, shifted, 1.0, e, vm, pm, c["tanfovx"], c["tanfovy"], 32, 32, shs, 1, cp,
         False, False)
     assert R2 == R and torch.equal(color2, color)
@@ -625,12 +625,12 @@ def test_kernel_sh_to_rgb_matches_reference_eval_sh_fixture(dgr):
     e = torch.empty(0)
     seen = np.zeros(P, bool)
     for deg in range(4):
-        R, color, radii, geom, binning, img = dgr._C.rasterize_gaussians(
+        R, color, radii, geom, binning, img = dgr._lib.rasterize_gaussians(
             torch.zeros(3, device=dev), g(z["means"]), e, torch.full((P, 1), 0.5, device=dev),
             torch.full((P, 3), 0.02, device=dev), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1).to(dev), 1.0, e,
             cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), math.tan(cam.FoVx / 2),
             math.tan(cam.FoVy / 2), 128, 128, g(z["shs"]), deg, g(z["campos"]), False, False)
-        st = decode_state(dgr._C, P, R, 128, 128, geom, binning, img)
+        st = decode_state(dgr._lib, P, R, 128, 128, geom, binning, img)
         vis = radii.cpu().numpy() > 0
         seen |= vis
         np.testing.assert_allclose(st["rgb"][vis], z["rgb_deg%d" % deg][vis], atol=2e-6, rtol=0)
@@ -724,8 +724,8 @@ def test_view_factored_sh_gradient_equals_sum_of_per_view_gradients(D, M, P, dgr
         torch.cuda.synchronize()
         d = dense.shaped()
         # one view, same backward run: the factored form of dL_dsh is the dense one, exactly
-        masked = dgr._C.masked_color_gradient(aux["geom"], aux["dL_dcolors"])
-        one = dgr._C.sh_gradient_from_views(scene.means3D, cam.camera_center.reshape(1, 3), masked.reshape(1, -1), D, M)
+        masked = dgr._lib.masked_color_gradient(aux["geom"], aux["dL_dcolors"])
+        one = dgr._lib.sh_gradient_from_views(scene.means3D, cam.camera_center.reshape(1, 3), masked.reshape(1, -1), D, M)
         assert torch.equal(one, d["dL_dsh"])
         # the exchange object run on its own backward pass (float atomics make two backward runs differ in the
         # last bits, hence a tolerance here)
@@ -735,7 +735,7 @@ def test_view_factored_sh_gradient_equals_sum_of_per_view_gradients(D, M, P, dgr
         # the backward pass handed the masked colour gradient over between its two stages: same bits as masking
         # that run's dL_dcolors afterwards, and the camera position sits behind it
         assert fact._early[0]
-        assert torch.equal(fact.local[0, :3 * P], dgr._C.masked_color_gradient(aux2["geom"], aux2["dL_dcolors"]).reshape(-1))
+        assert torch.equal(fact.local[0, :3 * P], dgr._lib.masked_color_gradient(aux2["geom"], aux2["dL_dcolors"]).reshape(-1))
         assert torch.equal(fact.local[0, 3 * P:3 * P + 3], cam.camera_center.reshape(3))
         fact.reduce(scene, cam, aux2)
         assert not fact._early[0]
@@ -756,11 +756,11 @@ def test_view_factored_sh_gradient_equals_sum_of_per_view_gradients(D, M, P, dgr
         dense_sum = d["dL_dsh"].clone() if dense_sum is None else dense_sum + d["dL_dsh"]
     # gathered-buffer layout: one row per view holding [masked colour gradient | camera position | pad]
     rows = torch.stack([torch.cat([m, cp, cp.new_zeros(1)]) for m, cp in zip(masked_rows, campos)])
-    got = dgr._C.sh_gradient_from_views(scene.means3D, rows[:, 3 * P:3 * P + 3], rows[:, :3 * P], D, M)
+    got = dgr._lib.sh_gradient_from_views(scene.means3D, rows[:, 3 * P:3 * P + 3], rows[:, :3 * P], D, M)
     torch.cuda.synchronize()
     assert torch.equal(got, dense_sum)
     with pytest.raises(RuntimeError):
-        dgr._C.sh_gradient_from_views(scene.means3D, rows[:, 3 * P:3 * P + 3], rows[:, :3 * P], 3, 9)
+        dgr._lib.sh_gradient_from_views(scene.means3D, rows[:, 3 * P:3 * P + 3], rows[:, :3 * P], 3, 9)
 
 
 def _rccl_single_rank_worker(rank, port, ret):

@@ -19,7 +19,7 @@ DEV = "cuda:0"
 @pytest.fixture(scope="module")
 def C():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _lib as _C
     _C.lib()
     return _C
 
@@ -233,7 +233,7 @@ def test_training_iterations_match_pytorch_assembly(C, config):
 def test_training_fits_a_rendered_target(C):
     """End to end: the image of a scene is the target, a copy of that scene with scrambled colours and dimmed
     opacities is trained on it from three views; the loss has to fall substantially and monotonically enough."""
-    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C as dC
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _lib as dC
     P, W, H, D = 3000, 128, 96, 3
     truth = synthetic.make_scene(P, D, (-3.6, -2.8), (1.3, 1.0, 1.3), seed=12, sh_coeffs=16).to(DEV)
     cams = [make_camera(W, H, synthetic.FOVX, e, device=DEV) for e in ((0.7, 0.5, -4.0), (-1.5, 0.4, -3.6), (1.4, -0.3, -3.7))]

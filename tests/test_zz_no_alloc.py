@@ -32,7 +32,7 @@ def _outputs(W, H, P):
 
 
 def _run_pair(L, P, W, H, seed, eye):
-    from neuralgaussiansplatting_amd.diff_gaussian_rasterization._C import _ptr, _stream
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization._lib import _ptr, _stream
     means, vm, pm, fv, campos = idxmap_case(P, W, H, seed=seed, eye=eye)
     t = lambda a: torch.tensor(a, device=DEV)
     means, vm, pm, fv, campos = t(means), t(vm), t(pm), t(fv), t(campos)
@@ -83,7 +83,7 @@ def test_static_idxmap_matches_workspace_variant_twice():
 
 
 def test_static_idxmap_empty_scene_and_limits():
-    from neuralgaussiansplatting_amd.diff_gaussian_rasterization._C import _ptr, _stream
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization._lib import _ptr, _stream
     L = _lib()
     dev = torch.device(DEV)
     W, H = 40, 24

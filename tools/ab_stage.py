@@ -21,7 +21,7 @@ def child(args):
     import torch
     sys.path.insert(0, ROOT)
     from neuralgaussiansplatting_amd import synthetic, view_parallel
-    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C
+    from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _lib as _C
     dev = torch.device("cuda:0")
     _C.lib().ngs_debug_depth_order({"auto": -1, "tile": 0, "gaussian": 1}[args.depth_order])
     P, W, H, D, M, ls, ext = synthetic.CONFIGS[args.config]

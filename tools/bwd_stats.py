@@ -6,7 +6,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from neuralgaussiansplatting_amd import synthetic, view_parallel
-from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _C
+from neuralgaussiansplatting_amd.diff_gaussian_rasterization import _lib as _C
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
 dev = torch.device("cuda:0")
