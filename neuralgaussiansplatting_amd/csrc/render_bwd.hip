@@ -165,17 +165,23 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
         // ---- the four rows walk their lists side by side ----
         // The records of the next step are requested before the arithmetic of the current one, so the LDS round
         // trips (list entry, then record) overlap with it.
+        // Slot addresses as 24-bit multiply-adds: the 48- and 36-byte strides would otherwise cost a quarter-rate
+        // 32/64-bit integer multiply each, twice per step.
+        const char* const rec_bytes = (const char*)&s_rec[0][0];
+        char* const acc_lane = (char*)&s_acc[0][0] + 4 * max(my_slot, 0);
         int j_next = 0 < my_n ? (int)my_list[0] : 0;
-        float4 p_next = s_rec[j_next][0], q_next = s_rec[j_next][1], col_next = s_rec[j_next][2];
+        const float4* r_next = (const float4*)(rec_bytes + __umul24((unsigned)j_next, (unsigned)sizeof(float4[3])));
+        float4 p_next = r_next[0], q_next = r_next[1], col_next = r_next[2];
         int j_after = 1 < my_n ? (int)my_list[1] : 0;
         for (int it = 0; it < steps; it++) {
             const bool have = it < my_n;
             const int j = j_next;
             const float4 p = p_next, q = q_next, col = col_next;
             j_next = j_after;
-            p_next = s_rec[j_next][0];
-            q_next = s_rec[j_next][1];
-            col_next = s_rec[j_next][2];
+            r_next = (const float4*)(rec_bytes + __umul24((unsigned)j_next, (unsigned)sizeof(float4[3])));
+            p_next = r_next[0];
+            q_next = r_next[1];
+            col_next = r_next[2];
             j_after = it + 2 < my_n ? (int)my_list[it + 2] : 0;
             const uint32_t pos = (uint32_t)(first - j);  // the reference's `contributor` after its decrement
             const v2f d = (v2f){p.x, p.y} - pix;  // {dx, dy}
@@ -237,7 +243,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             const float c07 = row_fold<DPP_QUAD_XOR2>(b03, b47, up2);
             const float c8 = row_pair_sum<DPP_QUAD_XOR2>(b8);
             const float total = row_fold<DPP_QUAD_XOR1>(c07, c8, up1);
-            if (have && my_slot >= 0 && total != 0.0f) atomicAdd(&s_acc[j][my_slot], total);
+            if (have && my_slot >= 0 && total != 0.0f)
+                atomicAdd((float*)(acc_lane + __umul24((unsigned)j, (unsigned)sizeof(float[ACC_USED]))), total);
         }
         __syncthreads();
         // Flush: 16 lanes per splat, lane c adds slot c of the splat's 64-byte accumulator row.

@@ -22,8 +22,9 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     const float4* __restrict__ rec_g, const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     float* __restrict__ out_color)
 {
-    // per wave, record k: [0] = {x, y, -, -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, -}
-    __shared__ float4 s_rec[NGS_TILE_PIX / 64][64][3];
+    // per wave, record k: [0] = {x, y, -, -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, -}; 64-byte slots, so
+    // the address of slot k is a shift-and-add (a 48-byte stride costs a quarter-rate 64-bit multiply-add per visit)
+    __shared__ float4 s_rec[NGS_TILE_PIX / 64][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int tx = tile % grid_x, ty = tile / grid_x;
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     const float sy0 = (float)(ty * NGS_TILE_H + (wave >> 1) * NGS_WAVE_H), sy1 = sy0 + (NGS_WAVE_H - 1);
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    float4(*rec)[3] = s_rec[wave];
+    float4(*rec)[4] = s_rec[wave];
 
     bool done = !inside;
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
