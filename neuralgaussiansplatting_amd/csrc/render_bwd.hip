@@ -102,7 +102,6 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     float rec_b = 0.0f;
     const v2f dp_rg = {dpr, dpg};
     const v2f ddel = {(float)(0.5 * W), (float)(0.5 * H)};  // d(pixel offset)/d(ndc)
-    const v2f pix = {pxf, pyf};
     // After the reduce-scatter the even lanes of a row hold partials 0..7 (index bits taken from lane bits 3, 2, 1
     // in that order of significance 1, 2, 4) and the odd lanes partial 8; lane 1 speaks for the odd ones.
     const bool up8 = (li & 8) != 0, up4 = (li & 4) != 0, up2 = (li & 2) != 0, up1 = (li & 1) != 0;
@@ -163,35 +162,22 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
         const int steps = max(max(n0, n1), max(n2, n3));
 
         // ---- the four rows walk their lists side by side ----
-        // The records of the next step are requested before the arithmetic of the current one, so the LDS round
-        // trips (list entry, then record) overlap with it.
         // Slot addresses as 24-bit multiply-adds: the 48- and 36-byte strides would otherwise cost a quarter-rate
         // 32/64-bit integer multiply each, twice per step.
         const char* const rec_bytes = (const char*)&s_rec[0][0];
         char* const acc_lane = (char*)&s_acc[0][0] + 4 * max(my_slot, 0);
-        int j_next = 0 < my_n ? (int)my_list[0] : 0;
-        const float4* r_next = (const float4*)(rec_bytes + __umul24((unsigned)j_next, (unsigned)sizeof(float4[3])));
-        float4 p_next = r_next[0], q_next = r_next[1], col_next = r_next[2];
-        int j_after = 1 < my_n ? (int)my_list[1] : 0;
-        for (int it = 0; it < steps; it++) {
+        // One step of a row: splat `j` of the batch (record p, q, col) against the row's 16 pixels.
+        auto step = [&](const int it, const int j, const float4 p, const float4 q, const float4 col) {
             const bool have = it < my_n;
-            const int j = j_next;
-            const float4 p = p_next, q = q_next, col = col_next;
-            j_next = j_after;
-            r_next = (const float4*)(rec_bytes + __umul24((unsigned)j_next, (unsigned)sizeof(float4[3])));
-            p_next = r_next[0];
-            q_next = r_next[1];
-            col_next = r_next[2];
-            j_after = it + 2 < my_n ? (int)my_list[it + 2] : 0;
             const uint32_t pos = (uint32_t)(first - j);  // the reference's `contributor` after its decrement
-            const v2f d = (v2f){p.x, p.y} - pix;  // {dx, dy}
-            const float dx = d.x, dy = d.y;
+            const float dx = p.x - pxf, dy = p.y - pyf;
+            const v2f d = {dx, dy};
             // same evaluation order as the forward pass (and the reference): alpha must come out bit-identical
             const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
             const float G = exp_nonpos(power);
             const float alpha = fminf(0.99f, q.w * G);
             const bool live = have && pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (wave_mask(live) == 0ull) continue;  // wave-uniform
+            if (wave_mask(live) == 0ull) return;  // wave-uniform
 
             // Every lane evaluates the body.  A dead lane (pixel that does not blend this splat) runs it with
             // alpha = 0, which leaves its state untouched without a single select: T / (1 - 0) = T, the
@@ -245,6 +231,30 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             const float total = row_fold<DPP_QUAD_XOR1>(c07, c8, up1);
             if (have && my_slot >= 0 && total != 0.0f)
                 atomicAdd((float*)(acc_lane + __umul24((unsigned)j, (unsigned)sizeof(float[ACC_USED]))), total);
+        };
+        auto record_of = [&](const int j) {
+            return (const float4*)(rec_bytes + __umul24((unsigned)j, (unsigned)sizeof(float4[3])));
+        };
+        // read ahead without asking whether an entry exists: a stale byte is a valid slot number, and `have` keeps
+        // a row from using what lies behind the end of its list
+        auto list_at = [&](const int k) { return (int)my_list[min(k, BWD_BATCH - 1)]; };
+        // Two steps per trip, the records of the two alternating between two sets of registers: step k requests
+        // the record of step k+1 and the list entry of step k+2 before its own arithmetic.
+        int ja = list_at(0), jb = list_at(1);
+        const float4* ra = record_of(ja);
+        float4 pa = ra[0], qa = ra[1], ca = ra[2];
+        for (int it = 0; it < steps; it += 2) {
+            const float4* rb = record_of(jb);
+            const float4 pb = rb[0], qb = rb[1], cb = rb[2];
+            const int jc = list_at(it + 2);
+            step(it, ja, pa, qa, ca);
+            if (it + 1 >= steps) break;
+            ra = record_of(jc);
+            pa = ra[0]; qa = ra[1]; ca = ra[2];
+            const int jd = list_at(it + 3);
+            step(it + 1, jb, pb, qb, cb);
+            ja = jc;
+            jb = jd;
         }
         __syncthreads();
         // Flush: 16 lanes per splat, lane c adds slot c of the splat's 64-byte accumulator row.
