@@ -47,6 +47,22 @@ __device__ __forceinline__ float row_pair_sum(float a)
 
 #define BWD_BATCH NGS_TILE_PIX  // splats staged per round
 
+#ifdef NGS_BWD_STATS
+// Diagnostic build: utilisation counters of the walk.  [0] wave-steps, [1] row-steps with an entry, [2] live
+// lane-steps, [3] wave-steps left at the early exit, [4] wave-batches, [5] sum over batches of the longest wave's
+// steps, [6] sum over batches and waves of steps, [7] staged splats.
+__device__ unsigned long long g_bwd_stats[8];
+extern "C" int ngs_debug_bwd_stats(unsigned long long* out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_stats), sizeof(g_bwd_stats)) != hipSuccess) return 1;
+    unsigned long long zero[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stats), zero, sizeof(zero)) != hipSuccess;
+}
+#define STAT(k, v) st[k] += (v)
+#else
+#define STAT(k, v)
+#endif
+
 __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
     const float4* __restrict__ splat_rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -111,6 +127,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     // Zero-based list positions tmax-1 ... 0 are walked in that order, BWD_BATCH per round;
     // staged slot s of round r holds list position tmax-1 - r*BWD_BATCH - s.
     const int rounds = (int)((tmax + BWD_BATCH - 1) / BWD_BATCH);
+#ifdef NGS_BWD_STATS
+    __shared__ int s_steps[4];
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int r = 0; r < rounds; r++) {
         __syncthreads();  // previous batch fully flushed before its LDS is reused
         const int first = (int)tmax - 1 - r * BWD_BATCH;  // list position of slot 0
@@ -177,7 +197,13 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             const float G = exp_nonpos(power);
             const float alpha = fminf(0.99f, q.w * G);
             const bool live = have && pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (wave_mask(live) == 0ull) return;  // wave-uniform
+            STAT(0, 1);
+            STAT(1, __popcll(wave_mask(have)) / 16);
+            STAT(2, __popcll(wave_mask(live)));
+            if (wave_mask(live) == 0ull) {
+                STAT(3, 1);
+                return;  // wave-uniform
+            }
 
             // Every lane evaluates the body.  A dead lane (pixel that does not blend this splat) runs it with
             // alpha = 0, which leaves its state untouched without a single select: T / (1 - 0) = T, the
@@ -256,7 +282,18 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             ja = jc;
             jb = jd;
         }
+#ifdef NGS_BWD_STATS
+        if (lane == 0) s_steps[wave] = steps;
+        st[4] += 1;
+#endif
         __syncthreads();
+#ifdef NGS_BWD_STATS
+        if (tid == 0) {
+            st[5] += max(max(s_steps[0], s_steps[1]), max(s_steps[2], s_steps[3]));
+            st[6] += s_steps[0] + s_steps[1] + s_steps[2] + s_steps[3];
+            st[7] += nb;
+        }
+#endif
         // Flush: 16 lanes per splat, lane c adds slot c of the splat's 64-byte accumulator row.
         const int c = tid & 15;
         for (int j = tid >> 4; j < nb; j += NGS_TILE_PIX / 16) {
@@ -267,6 +304,11 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             }
         }
     }
+#ifdef NGS_BWD_STATS
+    if (lane == 0)
+        for (int k = 0; k < 8; k++)
+            if (st[k]) atomicAdd(&g_bwd_stats[k], st[k]);
+#endif
 }
 
 void ngs_launch_render_bwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
