@@ -21,10 +21,55 @@
 // owns a contiguous run of entries (a multiple of four).
 __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, const uint32_t* __restrict__ in,
                                                                         uint32_t* __restrict__ out,
+                                                                        const uint32_t* __restrict__ bext,
                                                                         uint32_t* __restrict__ misc,
                                                                         unsigned long long* mailbox)
 {
     __shared__ uint32_t wave_tot[SCAN_THREADS / 64];
+    if (blockIdx.x == 1) {
+        // A second workgroup, beside the scan rather than inside it (the scan's registers are spoken for): the frame's
+        // depth bounds from the per-block ones, which hold the high halves of the depth bits, the smallest rounded
+        // down in the low 16 bits of a word, the largest rounded up in the high 16.
+        __shared__ uint32_t wave_lo[SCAN_THREADS / 64], wave_hi[SCAN_THREADS / 64];
+        uint32_t dlo = 0xffffu, dhi = 0u;
+        for (int base = 0; base < n; base += 4 * SCAN_THREADS) {
+            uint32_t e[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {  // four loads in flight per trip; 16 K blocks (4 M Gaussians) take one trip
+                const int i = base + c * SCAN_THREADS + (int)threadIdx.x;
+                e[c] = i < n ? bext[i] : 0xffffu;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                dlo = min(dlo, e[c] & 0xffffu);
+                dhi = max(dhi, e[c] >> 16);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            dlo = min(dlo, (uint32_t)__shfl_xor((int)dlo, o, 64));
+            dhi = max(dhi, (uint32_t)__shfl_xor((int)dhi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            wave_lo[threadIdx.x >> 6] = dlo;
+            wave_hi[threadIdx.x >> 6] = dhi;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            dlo = threadIdx.x < SCAN_THREADS / 64 ? wave_lo[threadIdx.x] : 0xffffu;
+            dhi = threadIdx.x < SCAN_THREADS / 64 ? wave_hi[threadIdx.x] : 0u;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) {
+                dlo = min(dlo, (uint32_t)__shfl_xor((int)dlo, o, 64));
+                dhi = max(dhi, (uint32_t)__shfl_xor((int)dhi, o, 64));
+            }
+            if (threadIdx.x == 0) {  // bounds of the visible depths' bits (not necessarily attained)
+                misc[NGS_MISC_DMIN] = dlo << 16;
+                misc[NGS_MISC_DMAX] = dhi << 16;
+            }
+        }
+        return;
+    }
     // A thread's run is a whole number of 16-byte groups; up to SCAN_REGS groups (8.4 M Gaussians) are fetched with
     // independent vector loads and stay in registers for the second sweep -- one memory round trip instead of one per
     // entry.  Longer runs fall back to two scalar sweeps.
@@ -158,13 +203,16 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
                                                                     const uint32_t* __restrict__ tiles,
                                                                     const uint32_t* __restrict__ block_offs,
                                                                     const uint32_t* __restrict__ order,
-                                                                    int grid_x, uint32_t* __restrict__ keys,
+                                                                    const float* __restrict__ depth,
+                                                                    const DepthRank dr, int grid_x,
+                                                                    uint32_t* __restrict__ keys,
                                                                     uint32_t* __restrict__ vals, uint32_t capacity,
                                                                     uint32_t* __restrict__ misc)
 {
     __shared__ uint32_t s_incl[NGS_GAUSS_BLOCK];  // per wave: inclusive prefix of tiles within the wave
     __shared__ uint2 s_rect[NGS_GAUSS_BLOCK];
-    __shared__ uint32_t s_id[NGS_GAUSS_BLOCK];
+    __shared__ uint2 s_id[NGS_GAUSS_BLOCK];  // x: list word (Gaussian index | low part of the depth rank), y: the
+                                             // high part of the rank, which goes into every key of the Gaussian
     __shared__ uint32_t s_wave_tot[NGS_GAUSS_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + tid;
@@ -173,7 +221,14 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
         cnt = tiles[idx];
         if (cnt) {
             s_rect[tid] = rect[idx];
-            s_id[tid] = order ? order[idx] : (uint32_t)idx;
+            uint32_t id = order ? order[idx] : (uint32_t)idx, rank = 0;
+            if (depth && dr.key_bits) {
+                const uint32_t dmin = misc[NGS_MISC_DMIN], dmax = misc[NGS_MISC_DMAX];
+                const uint32_t r = dr.rank(__float_as_uint(depth[idx]), dmin, dr.shift(dmin, dmax));
+                rank = dr.key_part(r);
+                id |= dr.word_part(r);
+            }
+            s_id[tid] = make_uint2(id, rank);
         }
     }
     const uint32_t incl = wave_incl_scan_u32(cnt, lane);
@@ -201,24 +256,26 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
         const uint32_t x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu;
         const uint32_t w = x1 - x0;
         const uint32_t ty = y0 + local / w, tx = x0 + local % w;
-        keys[(size_t)wave_base + k] = ty * (uint32_t)grid_x + tx;  // the depth half of the key joins in the per-tile sort
-        vals[(size_t)wave_base + k] = s_id[wave * 64 + j];
+        // the tile id above the high part of the depth rank (the low part rides in the list word)
+        const uint2 ir = s_id[wave * 64 + j];
+        keys[(size_t)wave_base + k] = ((ty * (uint32_t)grid_x + tx) << dr.key_bits) | ir.y;
+        vals[(size_t)wave_base + k] = ir.x;
     }
 }
 
 // rasterizer_impl.cu:116-138; `ranges` was zeroed by the caller.  L = min(*count, capacity).
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ count, int64_t capacity,
-                                                          const uint32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ keys, int qbits,
                                                           uint2* __restrict__ ranges)
 {
     const int64_t L = min((int64_t)*count, capacity);
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
-    const uint32_t cur = keys[idx];
+    const uint32_t cur = keys[idx] >> qbits;
     if (idx == 0) {
         ranges[cur].x = 0;
     } else {
-        const uint32_t prev = keys[idx - 1];
+        const uint32_t prev = keys[idx - 1] >> qbits;
         if (cur != prev) {
             ranges[prev].y = (uint32_t)idx;
             ranges[cur].x = (uint32_t)idx;
@@ -229,20 +286,23 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
 
 // The same with four keys per thread (one 16-byte load plus the key before them).
 __global__ __launch_bounds__(256) void tile_ranges_vec_kernel(const uint32_t* __restrict__ count, int64_t capacity,
-                                                              const uint32_t* __restrict__ keys,
+                                                              const uint32_t* __restrict__ keys, int qbits,
                                                               uint2* __restrict__ ranges)
 {
     const int64_t L = min((int64_t)*count, capacity);
     const int64_t first = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (first >= L) return;
     uint32_t k[4];
+    uint32_t prev = first > 0 ? keys[first - 1] : 0u;  // both loads in flight before either is used
     if (first + 4 <= L) {
         const uint4 v = *(const uint4*)(keys + first);
         k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
     } else {
         for (int j = 0; j < 4; j++) k[j] = first + j < L ? keys[first + j] : 0u;
     }
-    uint32_t prev = first > 0 ? keys[first - 1] : 0u;
+    prev >>= qbits;
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[j] >>= qbits;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int64_t idx = first + j;
@@ -261,10 +321,10 @@ __global__ __launch_bounds__(256) void tile_ranges_vec_kernel(const uint32_t* __
 }
 
 void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* block_sums, uint32_t* block_offs,
-                                uint32_t* misc, unsigned long long* mailbox)
+                                const uint32_t* block_depths, uint32_t* misc, unsigned long long* mailbox)
 {
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblocks, block_sums, block_offs,
-                       misc, mailbox);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(block_depths ? 2 : 1), dim3(SCAN_THREADS), 0, s, nblocks,
+                       block_sums, block_offs, block_depths, misc, mailbox);
 }
 
 void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, const uint2* rect,
@@ -274,26 +334,26 @@ void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const u
     hipLaunchKernelGGL(depth_order_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, order, tiles, rect, s_tiles,
                        s_rect, s_block_sums);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, s_block_sums, s_block_offs,
-                       (uint32_t*)nullptr, (unsigned long long*)nullptr);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr);
 }
 
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
-                          const uint32_t* order, int grid_x, uint32_t* keys, uint32_t* vals, int64_t capacity,
-                          uint32_t* misc)
+                          const uint32_t* order, const float* depth, const DepthRank& dr, int grid_x, uint32_t* keys,
+                          uint32_t* vals, int64_t capacity, uint32_t* misc)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
     hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, rect, tiles, block_offs, order,
-                       grid_x, keys, vals, (uint32_t)capacity, misc);
+                       depth, dr, grid_x, keys, vals, (uint32_t)capacity, misc);
 }
 
-void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* keys, int T,
-                            uint2* ranges, size_t clear_bytes)
+void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* keys, int qbits,
+                            int T, uint2* ranges, size_t clear_bytes)
 {
     (void)hipMemsetAsync(ranges, 0, clear_bytes > (size_t)T * sizeof(uint2) ? clear_bytes : (size_t)T * sizeof(uint2), s);
     if (capacity > 0 && (uintptr_t)keys % 16 == 0)
         hipLaunchKernelGGL(tile_ranges_vec_kernel, dim3((unsigned)((capacity + 1023) / 1024)), dim3(256), 0, s, count,
-                           capacity, keys, ranges);
+                           capacity, keys, qbits, ranges);
     else if (capacity > 0)
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, s, count,
-                           capacity, keys, ranges);
+                           capacity, keys, qbits, ranges);
 }

@@ -312,13 +312,14 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     prof_begin(ps, ST_PREPROCESS, st);
     ngs_launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, raw, shs,
                               cov3D_precomp, colors_precomp, cam, prefiltered, radii, rec, depth, rect, tiles, clamped,
-                              block_sums, misc, dkeys[0], order[0]);
+                              block_sums, (uint32_t*)(gb + gl.block_depths), misc, dkeys[0], order[0]);
     prof_end(ps, ST_PREPROCESS, st);
     NGS_STAGE("preprocess");
     prof_begin(ps, ST_SCAN, st);
     Mailbox* mb = mailbox_get();
     if (mb) __atomic_store_n(mb->host, ~0ull, __ATOMIC_RELEASE);
-    ngs_launch_scan_block_sums(st, nblocks, block_sums, block_offs, misc, mb ? mb->dev : nullptr);
+    ngs_launch_scan_block_sums(st, nblocks, block_sums, block_offs, (const uint32_t*)(gb + gl.block_depths), misc,
+                               mb ? mb->dev : nullptr);
     prof_end(ps, ST_SCAN, st);
     NGS_STAGE("scan");
 
@@ -354,16 +355,21 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     // are emitted -- 14 small launches whose cost follows P -- or a sort of every tile's list afterwards -- two
     // launches whose cost follows the instance count and rises steeply once lists outgrow a workgroup (4096
     // entries).  Measured on MI355X the first costs about 90 us + 48 us per million Gaussians, the second about
-    // 12 us + 10.5 us per million instances while no list passes 4096 entries (0.13 ms at 1500 per tile on average
-    // and 12 M instances, 0.19 ms at 2000 and 16.5 M; 0.53 ms at 2900 and 24 M, where the longest lists do).
+    // 12 us + 6 us per million instances while no list passes 4096 entries and the instances carry their depth rank
+    // (0.085 ms at 1500 per tile on average and 12 M instances), rising steeply where the longest lists do (2900 per
+    // tile on average and 24 M instances).
     bool depth_first;
     {
         const double inst = (double)capacity, per_tile = inst / (double)T;
-        const double by_tile = 12.0 + 10.5e-6 * inst * (per_tile > 2600.0 ? 1.0 + (per_tile - 2600.0) / 300.0 : 1.0);
+        const double by_tile = 12.0 + 6.1e-6 * inst * (per_tile > 2600.0 ? 1.0 + (per_tile - 2600.0) / 150.0 : 1.0);
         const double by_gaussian = 90.0 + 48e-6 * (double)P;
         depth_first = by_gaussian < by_tile;
         if (g_depth_order_choice >= 0) depth_first = g_depth_order_choice != 0;
     }
+    // Instances emitted in index order carry a depth rank beside the tile id of their key and the Gaussian index of
+    // their list word, so that the per-tile sort reads it with the list instead of gathering a depth per entry.
+    const DepthRank dr = ngs_depth_rank(P, tile_bits, !depth_first);
+    const int qbits = dr.key_bits;
     if (depth_first) {
         // Gaussians in depth order (ties in index order: the passes are stable), then their tile counts, rectangles
         // and instance offsets in that order.
@@ -386,26 +392,26 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         if (capacity > 0) {
             prof_begin(ps, ST_DUPLICATE, st);
             if (depth_first)
-                ngs_launch_duplicate(st, P, s_rect, s_tiles, s_block_offs, order[0], cam.grid_x, tkeys[in_buf],
-                                     vals[in_buf], capacity, misc);
+                ngs_launch_duplicate(st, P, s_rect, s_tiles, s_block_offs, order[0], nullptr, dr, cam.grid_x,
+                                     tkeys[in_buf], vals[in_buf], capacity, misc);
             else
-                ngs_launch_duplicate(st, P, rect, tiles, block_offs, nullptr, cam.grid_x, tkeys[in_buf], vals[in_buf],
-                                     capacity, misc);
+                ngs_launch_duplicate(st, P, rect, tiles, block_offs, nullptr, depth, dr, cam.grid_x, tkeys[in_buf],
+                                     vals[in_buf], capacity, misc);
             prof_end(ps, ST_DUPLICATE, st);
             NGS_STAGE("duplicateWithKeys");
             prof_begin(ps, ST_SORT, st);
-            ngs_launch_sort_tile_bits(st, misc, capacity, tkeys, vals, hist, totals, tile_bits);
+            ngs_launch_sort_tile_bits(st, misc, capacity, tkeys, vals, hist, totals, tile_bits, qbits);
             prof_end(ps, ST_SORT, st);
             NGS_STAGE("sort");
         }
         prof_begin(ps, ST_RANGES, st);
         // the same fill also clears the counter of the per-tile sort's work list, which follows the ranges
-        ngs_launch_tile_ranges(st, misc, capacity, tkeys[0], T, ranges, il.hard + 16 - il.ranges);
+        ngs_launch_tile_ranges(st, misc, capacity, tkeys[0], qbits, T, ranges, il.hard + 16 - il.ranges);
         prof_end(ps, ST_RANGES, st);
         NGS_STAGE("identifyTileRanges");
         if (capacity > 0 && !depth_first) {
             prof_begin(ps, ST_SEGSORT, st);
-            ngs_launch_sort_segments(st, T, ranges, depth, tkeys, vals, (uint32_t*)(ib + il.hard));
+            ngs_launch_sort_segments(st, T, ranges, depth, tkeys, vals, (uint32_t*)(ib + il.hard), dr, misc);
             prof_end(ps, ST_SEGSORT, st);
             NGS_STAGE("sort (depth)");
         }

@@ -17,6 +17,8 @@
 #define NGS_ALIGN 256
 
 // Slots of one accumulator row filled by the backward compositing kernel.
+#define NGS_MISC_DMIN 2
+#define NGS_MISC_DMAX 3
 enum { ACC_DX = 0, ACC_DY, ACC_CON_A, ACC_CON_B, ACC_CON_C, ACC_OPAC, ACC_R, ACC_G, ACC_B, ACC_USED };
 
 // ---------------------------------------------------------------------------
@@ -37,7 +39,9 @@ struct GeomLayout {
     size_t block_sums; // u32   [ceil(P/256)] tiles touched per 256-Gaussian block
     size_t block_offs; // u32   [ceil(P/256)] exclusive prefix of block_sums
     size_t misc;       // u32   [8]  [0] total instances R, [1] error flags (1 prefiltered point culled, 2 count
-                       //            beyond 2^31-1, 4 count beyond the binning buffer's capacity)
+                       //            beyond 2^31-1, 4 count beyond the binning buffer's capacity), [2] / [3] a lower /
+                       //            upper bound of the depth bits of the visible Gaussians, within 2^16 of the extremes
+                       //            (0xffff0000 / 0 when there is none)
     size_t acc;        // float [P][16] gradient accumulator rows (backward)
     // Depth order of the Gaussians (forward only): instances are emitted in this order, so that the stable
     // tile-level sort leaves every tile's list sorted by depth.
@@ -49,6 +53,9 @@ struct GeomLayout {
     size_t s_block_offs; // u32 [ceil(P/256)] exclusive prefix of s_block_sums
     size_t dhist;      // u32   [256 * sort_blocks(P)] histogram of the depth passes
     size_t dtotals;    // u32   [256]
+    size_t block_depths; // u32 [ceil(P/256)] depth bounds of the block's visible Gaussians, high halves of the depth
+                       //            bits: low 16 = smallest, rounded down; high 16 = largest, rounded up (0xffff and 0
+                       //            for a block without a visible Gaussian)
     size_t total;
 };
 
@@ -100,8 +107,57 @@ static inline GeomLayout ngs_geom_layout(size_t P)
     l.s_block_offs = o; o = ngs_align_up(o + nb * 4);
     l.dhist = o; o = ngs_align_up(o + ((P + NGS_SORT_TILE - 1) / NGS_SORT_TILE) * 256 * 4);
     l.dtotals = o; o = ngs_align_up(o + 256 * 4);
+    l.block_depths = o; o = ngs_align_up(o + nb * 4);
     l.total = o + NGS_ALIGN;
     return l;
+}
+
+// Depth rank that rides with every instance through the tile-level sort, so that the per-tile depth sort reads it
+// with the list instead of gathering a depth per entry: r = (depth bits - a lower bound of the frame's) >> shift,
+// `key_bits` + `word_bits` bits long.  Its high key_bits sit in the low bits of the instance's 32-bit sort key, below
+// the tile id (the tile-level passes skip them); its low word_bits sit in the instance's list word above the
+// idx_bits the Gaussian index needs.  The bit pattern of a positive float grows with its value, so r never decreases
+// with depth, and with shift == 0 (the frame's depth span fits the rank) it orders exactly like the depth bits.
+// key_bits == 0: no rank is carried (too few bits beside the tile id to be worth it).
+struct DepthRank {
+    int key_bits, word_bits, idx_bits;
+    __host__ __device__ uint32_t idx_mask() const { return idx_bits >= 32 ? 0xffffffffu : (1u << idx_bits) - 1u; }
+    __host__ __device__ int shift(uint32_t dmin, uint32_t dmax) const
+    {
+        const uint32_t span = dmax > dmin ? dmax - dmin : 0u;
+        const int len = span ? 32 - __builtin_clz(span) : 0;  // bit length of the span
+        return len > key_bits + word_bits ? len - (key_bits + word_bits) : 0;
+    }
+    // the rank of a depth, and its two parts as they are stored
+    __host__ __device__ uint32_t rank(uint32_t bits, uint32_t dmin, int sh) const
+    {
+        return ((bits - dmin) >> sh) & ((1u << (key_bits + word_bits)) - 1u);  // the mask changes nothing for a depth
+    }                                                                           // between the frame's extremes
+    __host__ __device__ uint32_t key_part(uint32_t r) const { return r >> word_bits; }
+    __host__ __device__ uint32_t word_part(uint32_t r) const
+    {
+        return word_bits ? (r & ((1u << word_bits) - 1u)) << idx_bits : 0u;
+    }
+    // and back: the rank from a sort key and a list word
+    __host__ __device__ uint32_t join(uint32_t key, uint32_t word) const
+    {
+        const uint32_t hi = key & ((1u << key_bits) - 1u);
+        return word_bits ? (hi << word_bits) | (word >> idx_bits) : hi;
+    }
+};
+// P Gaussians, tile ids of tile_bits bits.  The rank is at most 31 bits long (the span of positive floats).
+static inline DepthRank ngs_depth_rank(int P, int tile_bits, bool wanted)
+{
+    DepthRank d = {0, 0, 32};
+    if (!wanted || 32 - tile_bits < 12) return d;
+    d.key_bits = 32 - tile_bits;
+    if (d.key_bits > 31) d.key_bits = 31;
+    int idx_bits = 1;
+    while (idx_bits < 32 && ((uint64_t)1 << idx_bits) < (uint64_t)P) idx_bits++;
+    d.word_bits = 32 - idx_bits;
+    if (d.word_bits > 31 - d.key_bits) d.word_bits = 31 - d.key_bits;
+    d.idx_bits = d.word_bits ? idx_bits : 32;
+    return d;
 }
 
 static inline ImageLayout ngs_image_layout(int W, int H)
@@ -216,13 +272,14 @@ void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* 
                                const float* rots, const float* opac, int raw, const float* shs, const float* cov_pre,
                                const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* rec,
                                float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
-                               uint32_t* block_sums, uint32_t* misc, uint32_t* dkeys, uint32_t* order);
+                               uint32_t* block_sums, uint32_t* block_depths, uint32_t* misc, uint32_t* dkeys,
+                               uint32_t* order);
 void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const float* view, uint8_t* present);
 // binning.hip
 // mailbox: device-visible address of a 64-bit word in pinned host memory that receives (error flag << 32 | total),
-// or NULL.
+// or NULL.  block_depths: per-block depth bounds (GeomLayout::block_depths), reduced into misc[NGS_MISC_DMIN / _DMAX].
 void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* block_sums, uint32_t* block_offs,
-                                uint32_t* misc, unsigned long long* mailbox);
+                                const uint32_t* block_depths, uint32_t* misc, unsigned long long* mailbox);
 // The stages between the scan and the compositing take the instance count from DEVICE memory (`count`, the word
 // the scan kernel wrote) and a capacity: launches are sized by the capacity, kernels work on min(count, capacity)
 // instances, so they can be queued before the host knows the count and never step outside the buffer.
@@ -231,25 +288,30 @@ void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* bloc
 // k-th Gaussian IN DEPTH ORDER at its offset; the value of each instance is order[k].
 void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, const uint2* rect,
                             uint32_t* s_tiles, uint2* s_rect, uint32_t* s_block_sums, uint32_t* s_block_offs);
+// Keys are (tile id << dr.key_bits) | high part of the depth rank, list words Gaussian index | low part of the rank
+// << dr.idx_bits (see DepthRank); dr.key_bits == 0: the tile id and the index alone.
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
-                          const uint32_t* order, int grid_x, uint32_t* tile_keys, uint32_t* vals, int64_t capacity,
-                          uint32_t* misc);
+                          const uint32_t* order, const float* depth, const DepthRank& dr, int grid_x,
+                          uint32_t* tile_keys, uint32_t* vals, int64_t capacity, uint32_t* misc);
 // clear_bytes: bytes to zero starting at `ranges` (at least 8 T; the caller extends it over the counter that follows)
-void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* tile_keys, int T,
-                            uint2* ranges, size_t clear_bytes);
-// radix_sort.hip: stable LSD radix sort of (32-bit key, 32-bit value) pairs on the low `bits` bits of the key,
-// result in keys[0]/vals[0].  It runs twice per frame: over the Gaussians' depth bits (all 32), and over the tile
+// the tile id of a key is key >> qbits
+void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* tile_keys, int qbits,
+                            int T, uint2* ranges, size_t clear_bytes);
+// radix_sort.hip: stable LSD radix sort of (32-bit key, 32-bit value) pairs on bits [first_bit, first_bit + bits) of
+// the key, result in keys[0]/vals[0].  It runs twice per frame: over the Gaussians' depth bits (all 32), and over the tile
 // ids of the instances emitted in that depth order -- stable, so every tile's list comes out sorted by depth.
 // ngs_sort_input_buffer returns the buffer index (0 or 1) the unsorted input must be written to.
 // `count` (device) may be NULL: the number of pairs is then `capacity` itself (the caller knows it).
 int ngs_sort_input_buffer(int bits);
 void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
-                               uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits);
+                               uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits, int first_bit = 0);
 // Per-tile depth sort of vals[0] (lists in index order inside each tile) by the depth of the listed Gaussians;
 // keys[] and vals[1] are scratch for lists that do not fit a workgroup.
-// hard: u32[4 + 2T] with hard[0] == hard[1] == 0 on entry (see ImageLayout).
+// hard: u32[4 + 2T] with hard[0] == hard[1] == 0 on entry (see ImageLayout).  dr.key_bits != 0: keys[0] and vals[0]
+// carry every entry's depth rank (the list leaves without it); misc: the geometry buffer's word array (depth extremes
+// in [2], [3]).
 void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
-                              uint32_t* const vals[2], uint32_t* hard);
+                              uint32_t* const vals[2], uint32_t* hard, const DepthRank& dr, const uint32_t* misc);
 // render_fwd.hip
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,

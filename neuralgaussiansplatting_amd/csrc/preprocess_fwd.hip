@@ -90,10 +90,11 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ cov_pre, const float* __restrict__ col_pre, const NgsCamera cam,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, int prefiltered,
     int* __restrict__ radii, float4* __restrict__ rec, float* __restrict__ depth, uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint8_t* __restrict__ clamped,
-    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ misc, uint32_t* __restrict__ dkeys,
-    uint32_t* __restrict__ order)
+    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_depths, uint32_t* __restrict__ misc,
+    uint32_t* __restrict__ dkeys, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t wave_tot[NGS_GAUSS_BLOCK / 64];
+    __shared__ uint32_t wave_dmin[NGS_GAUSS_BLOCK / 64], wave_dmax[NGS_GAUSS_BLOCK / 64];
     __shared__ float4 s_sh[EAGER ? (NGS_GAUSS_BLOCK / 64) * SH_WAVE_F4 : 1];
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
     uint32_t my_tiles = 0;
@@ -266,9 +267,28 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     }
     // Tiles touched by this block of 256 Gaussians: the first level of the instance-offset scan.
     const uint32_t ws = wave_sum_u32(my_tiles);
-    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = ws;
+    // Depth extremes of the block's visible Gaussians: the frame's extremes fix the scale of the depth rank that
+    // rides in the instances' sort keys.
+    uint32_t dlo = live ? __float_as_uint(view_z) : 0xffffffffu, dhi = live ? __float_as_uint(view_z) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dlo = min(dlo, (uint32_t)__shfl_xor((int)dlo, o, 64));
+        dhi = max(dhi, (uint32_t)__shfl_xor((int)dhi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wave_tot[threadIdx.x >> 6] = ws;
+        wave_dmin[threadIdx.x >> 6] = dlo;
+        wave_dmax[threadIdx.x >> 6] = dhi;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        // bounds, 16 bits each: the smallest depth's high half, and the largest's plus one (a visible depth is a
+        // positive finite float, so that still fits); 0xffff and 0 for a block without a visible Gaussian
+        const uint32_t blo = min(min(wave_dmin[0], wave_dmin[1]), min(wave_dmin[2], wave_dmin[3]));
+        const uint32_t bhi = max(max(wave_dmax[0], wave_dmax[1]), max(wave_dmax[2], wave_dmax[3]));
+        block_depths[blockIdx.x] = (blo >> 16) | (bhi ? min((bhi >> 16) + 1u, 0xffffu) << 16 : 0u);
+    }
 }
 
 // rasterizer_impl.cu:54-66: present[i] = view-space z > 0.2
@@ -286,7 +306,8 @@ void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* 
                                const float* rots, const float* opac, int raw, const float* shs, const float* cov_pre,
                                const float* col_pre, const NgsCamera& cam, int prefiltered, int* radii, float4* rec,
                                float* depth, uint2* rect, uint32_t* tiles, uint8_t* clamped,
-                               uint32_t* block_sums, uint32_t* misc, uint32_t* dkeys, uint32_t* order)
+                               uint32_t* block_sums, uint32_t* block_depths, uint32_t* misc, uint32_t* dkeys,
+                               uint32_t* order)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
     const bool eager = !cov_pre && !col_pre && shs && scales && rots && D == 3 && M == 16 && (uintptr_t)shs % 16 == 0 &&
@@ -294,11 +315,11 @@ void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* 
     if (eager)
         hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales, mod, rots,
                        opac, raw, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered, radii, rec, depth, rect, tiles, clamped,
-                       block_sums, misc, dkeys, order);
+                       block_sums, block_depths, misc, dkeys, order);
     else
         hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, D, M, means, scales,
                            mod, rots, opac, raw, shs, cov_pre, col_pre, cam, cam.view, cam.proj, cam.campos, prefiltered,
-                           radii, rec, depth, rect, tiles, clamped, block_sums, misc, dkeys, order);
+                           radii, rec, depth, rect, tiles, clamped, block_sums, block_depths, misc, dkeys, order);
 }
 
 void ngs_launch_mark_visible(hipStream_t s, int P, const float* means, const float* view, uint8_t* present)

@@ -260,15 +260,28 @@ __device__ __forceinline__ void block_rank_pass(const uint32_t (&key)[ITEMS], in
 // lists, or a bucket with more than SEG_BUCKET_LIMIT entries: many equal or nearly equal depths) are appended to
 // work list `out` for the next kernel.
 // work lists (see ImageLayout::hard): word 0 / 1 = length of list 0 / 1, list k at words 4 + k T.
+//
+// RANKED: the entries bring their depth along instead of having it gathered, one scattered word per entry, from the
+// per-Gaussian depth array: a rank r = (depth bits - smallest depth bits of the frame) >> shift (see DepthRank) is
+// split over the low bits of the entry's sort key and the bits of its list word above the Gaussian index, both of
+// which this kernel reads as contiguous streams.  When the frame's depth span fits the rank's bits (shift == 0, the
+// usual case) the rank orders exactly like the depth bits and is the sort key here; when it does not, the kernel
+// gathers the depths after all.  Either way the list leaves as plain Gaussian indices.
 #define SEG_ITEMS 16
 #define SEG_BUCKET_LIMIT 128
-template <int THREADS>
+template <int THREADS, bool RANKED>
 __global__ __launch_bounds__(THREADS) void segment_sort_bucket_kernel(int T, const uint2* __restrict__ ranges,
                                                                       const float* __restrict__ depth,
+                                                                      const uint32_t* __restrict__ keys0,
+                                                                      const DepthRank dr,
+                                                                      const uint32_t* __restrict__ misc,
                                                                       uint32_t* __restrict__ vals0,
                                                                       uint32_t* __restrict__ hard, int in, int out)
 {
     constexpr int CAP = SEG_ITEMS * THREADS, NB = 8 * THREADS, WAVES = THREADS / 64;
+    const uint32_t idx_mask = RANKED ? dr.idx_mask() : 0xffffffffu;
+    // block-uniform: the rank in the keys is as good as the depth
+    const bool exact = RANKED && dr.shift(misc[NGS_MISC_DMIN], misc[NGS_MISC_DMAX]) == 0;
     __shared__ uint32_t s_cnt[NB];   // bucket sizes, then each bucket's cursor (its end once all entries sit)
     __shared__ uint32_t s_key[CAP];  // depth bits grouped by bucket
     __shared__ uint16_t s_slot[CAP]; // and where in the incoming list each came from
@@ -279,12 +292,15 @@ __global__ __launch_bounds__(THREADS) void segment_sort_bucket_kernel(int T, con
         const uint32_t tile = in < 0 ? w : hard[4 + (size_t)in * T + w];
         const uint2 range = ranges[tile];
         const int n = (int)(range.y - range.x);
-        if (n < 2) continue;  // block-uniform, like every branch on n below
+        const size_t lo = range.x;
+        if (n < 2) {  // block-uniform, like every branch on n below
+            if (RANKED && n == 1 && tid == 0) vals0[lo] &= idx_mask;
+            continue;
+        }
         if (n > CAP) {
             if (tid == 0) hard[4 + (size_t)out * T + atomicAdd(&hard[out], 1u)] = tile;
             continue;
         }
-        const size_t lo = range.x;
         __syncthreads();  // a previous trip's readers of the LDS tables are done
 #pragma unroll
         for (int j = 0; j < NB / THREADS; j++) s_cnt[j * THREADS + tid] = 0;
@@ -293,6 +309,7 @@ __global__ __launch_bounds__(THREADS) void segment_sort_bucket_kernel(int T, con
         for (int i = 0; i < SEG_ITEMS; i++) {
             const int slot = i * THREADS + tid;
             val[i] = (i * THREADS < n && slot < n) ? vals0[lo + slot] : 0u;
+            if (RANKED) key[i] = (exact && i * THREADS < n && slot < n) ? keys0[lo + slot] : 0u;
         }
         // all list entries are on their way before the first dependent depth gather is issued
         uint32_t kmin = ~0u, kmax = 0u;
@@ -300,7 +317,13 @@ __global__ __launch_bounds__(THREADS) void segment_sort_bucket_kernel(int T, con
         for (int i = 0; i < SEG_ITEMS; i++) {
             const int slot = i * THREADS + tid;
             if (i * THREADS < n && slot < n) {
-                key[i] = __float_as_uint(depth[val[i]]);
+                if (RANKED) {
+                    const uint32_t word = val[i];
+                    val[i] = word & idx_mask;
+                    key[i] = exact ? dr.join(key[i], word) : __float_as_uint(depth[val[i]]);
+                } else {
+                    key[i] = __float_as_uint(depth[val[i]]);
+                }
                 kmin = min(kmin, key[i]);
                 kmax = max(kmax, key[i]);
             } else {
@@ -317,7 +340,16 @@ __global__ __launch_bounds__(THREADS) void segment_sort_bucket_kernel(int T, con
 #pragma unroll
         for (int v = 0; v < WAVES; v++) { kmin = min(kmin, s_red[0][v]); kmax = max(kmax, s_red[1][v]); }
         const uint32_t span = kmax - kmin;
-        if (span == 0u) continue;  // one depth for the whole list: the incoming order is the answer
+        if (span == 0u) {  // one depth for the whole list: the incoming order is the answer
+            if (RANKED) {
+#pragma unroll
+                for (int i = 0; i < SEG_ITEMS; i++) {
+                    const int slot = i * THREADS + tid;
+                    if (i * THREADS < n && slot < n) vals0[lo + slot] = val[i];
+                }
+            }
+            continue;
+        }
         int sh = 32 - __clz((int)span);  // bit length of the span
         sh = max(0, sh - (THREADS == 256 ? 11 : 12));  // span >> sh < NB
         static_assert(THREADS == 256 || THREADS == 512, "NB = 8 THREADS is 2^11 or 2^12");
@@ -389,7 +421,8 @@ __global__ __launch_bounds__(THREADS) void segment_sort_bucket_kernel(int T, con
 __global__ __launch_bounds__(ST) void segment_sort_long_kernel(int T, const uint2* __restrict__ ranges,
                                                                const float* __restrict__ depth, uint32_t* keys0,
                                                                uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
-                                                               const uint32_t* __restrict__ hard, int in)
+                                                               const uint32_t* __restrict__ hard, int in,
+                                                               uint32_t idx_mask)
 {
     __shared__ uint32_t s_cnt[SWAVES][256];
     __shared__ uint32_t s_start[256];
@@ -414,7 +447,8 @@ __global__ __launch_bounds__(ST) void segment_sort_long_kernel(int T, const uint
             __syncthreads();
             // the first pass has no keys yet: it builds them from the depth of each listed Gaussian
             for (int i = tid; i < n; i += ST) {
-                const uint32_t k = pass == 0 ? __float_as_uint(depth[vsrc[lo + i]]) : ksrc[lo + i];
+                // incoming list words may carry rank bits above the Gaussian index; the first pass strips them
+                const uint32_t k = pass == 0 ? __float_as_uint(depth[vsrc[lo + i] & idx_mask]) : ksrc[lo + i];
                 atomicAdd(&s_cnt[0][(k >> shift) & 0xffu], 1u);
             }
             __syncthreads();
@@ -435,7 +469,7 @@ __global__ __launch_bounds__(ST) void segment_sort_long_kernel(int T, const uint
                 for (int i = 0; i < SI; i++) {
                     const int slot = wave * quota + i * 64 + lane;
                     const bool valid = slot < m;
-                    val[i] = valid ? vsrc[lo + c0 + slot] : 0u;
+                    val[i] = valid ? vsrc[lo + c0 + slot] & (pass == 0 ? idx_mask : 0xffffffffu) : 0u;
                     key[i] = !valid ? ~0u : pass == 0 ? __float_as_uint(depth[val[i]]) : ksrc[lo + c0 + slot];
                 }
                 uint32_t tot;
@@ -465,7 +499,7 @@ static int tile_passes(int bits) { return (bits + 7) / 8; }
 int ngs_sort_input_buffer(int bits) { return tile_passes(bits) & 1; }
 
 void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
-                               uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits)
+                               uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits, int first_bit)
 {
     if (capacity <= 0) return;
     const int nblocks = (int)((capacity + STILE - 1) / STILE);
@@ -476,11 +510,11 @@ void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t cap
     for (int shift = 0, width; shift < bits; shift += width, passes_left--) {
         width = (bits - shift + passes_left - 1) / passes_left;
         const uint32_t mask = (1u << width) - 1u;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur], shift, mask,
-                           nblocks, hist);
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur],
+                           first_bit + shift, mask, nblocks, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(SCAN_T), 0, s, nblocks, hist, totals);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur], vals[cur],
-                           keys[cur ^ 1], vals[cur ^ 1], shift, mask, nblocks, hist, totals);
+                           keys[cur ^ 1], vals[cur ^ 1], first_bit + shift, mask, nblocks, hist, totals);
         cur ^= 1;
     }
 }
@@ -493,9 +527,14 @@ void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t cap
 // once lists outgrow a workgroup), the Gaussian-level sort's with the number of Gaussians: the forward pass picks
 // whichever is cheaper for the call.
 void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
-                              uint32_t* const vals[2], uint32_t* hard)
+                              uint32_t* const vals[2], uint32_t* hard, const DepthRank& dr, const uint32_t* misc)
 {
-    hipLaunchKernelGGL(segment_sort_bucket_kernel<ST>, dim3(T), dim3(ST), 0, s, T, ranges, depth, vals[0], hard, -1, 0);
+    if (dr.key_bits > 0)
+        hipLaunchKernelGGL((segment_sort_bucket_kernel<ST, true>), dim3(T), dim3(ST), 0, s, T, ranges, depth, keys[0],
+                           dr, misc, vals[0], hard, -1, 0);
+    else
+        hipLaunchKernelGGL((segment_sort_bucket_kernel<ST, false>), dim3(T), dim3(ST), 0, s, T, ranges, depth, keys[0],
+                           dr, misc, vals[0], hard, -1, 0);
     hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T < 512 ? T : 512), dim3(ST), 0, s, T, ranges, depth, keys[0],
-                       vals[0], keys[1], vals[1], hard, 0);
+                       vals[0], keys[1], vals[1], hard, 0, dr.key_bits > 0 ? dr.idx_mask() : 0xffffffffu);
 }
