@@ -408,9 +408,11 @@ int ngs_profile_read(double* total_ms, long long* launches, int reset);
 /*
  * For tests and measurements: where ngs_rasterize_forward takes the depth order of the tile lists from.  -1 (the
  * default): it chooses per call from P and the instance count; 0: always the per-tile depth sort after the
- * tile-level sort; 1: always the depth sort of the Gaussians before their instances are emitted.  The lists are the
- * same either way.  Process-wide, not thread-safe.  No counterpart in the reference (which sorts all instances on
- * the full 64-bit key, rasterizer_impl.cu:303-308).
+ * tile-level sort; 1: always the depth sort of the Gaussians before their instances are emitted; 2 and 3: the
+ * per-tile depth sort with the depth rank that instances carry through the tile-level sort made too coarse to stand
+ * in for the depth (so that every depth is fetched after all), and with no rank carried at all.  The lists are the
+ * same in every case.  Process-wide, not thread-safe.  No counterpart in the reference (which sorts all instances
+ * on the full 64-bit key, rasterizer_impl.cu:303-308).
  */
 void ngs_debug_depth_order(int choice);
 

@@ -251,7 +251,8 @@ extern "C" int ngs_state_layout(int P, long long R, int W, int H, size_t* geomet
 }
 
 // -1: the forward pass chooses where the depth order comes from; 0 / 1 force the per-tile sort / the sort of the
-// Gaussians (tests and measurements; see ngs_debug_depth_order).
+// Gaussians; 2 / 3: the per-tile sort with a depth rank too coarse to stand in for the depth / with no rank at all
+// (tests and measurements; see ngs_debug_depth_order).
 static int g_depth_order_choice = -1;
 extern "C" void ngs_debug_depth_order(int choice) { g_depth_order_choice = choice; }
 
@@ -364,11 +365,12 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         const double by_tile = 12.0 + 6.1e-6 * inst * (per_tile > 2600.0 ? 1.0 + (per_tile - 2600.0) / 150.0 : 1.0);
         const double by_gaussian = 90.0 + 48e-6 * (double)P;
         depth_first = by_gaussian < by_tile;
-        if (g_depth_order_choice >= 0) depth_first = g_depth_order_choice != 0;
+        if (g_depth_order_choice >= 0) depth_first = g_depth_order_choice == 1;
     }
     // Instances emitted in index order carry a depth rank beside the tile id of their key and the Gaussian index of
     // their list word, so that the per-tile sort reads it with the list instead of gathering a depth per entry.
-    const DepthRank dr = ngs_depth_rank(P, tile_bits, !depth_first);
+    DepthRank dr = ngs_depth_rank(P, tile_bits, !depth_first && g_depth_order_choice != 3);
+    if (g_depth_order_choice == 2) dr.min_shift = 20;
     const int qbits = dr.key_bits;
     if (depth_first) {
         // Gaussians in depth order (ties in index order: the passes are stable), then their tile counts, rectangles

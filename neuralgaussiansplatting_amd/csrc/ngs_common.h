@@ -121,12 +121,14 @@ static inline GeomLayout ngs_geom_layout(size_t P)
 // key_bits == 0: no rank is carried (too few bits beside the tile id to be worth it).
 struct DepthRank {
     int key_bits, word_bits, idx_bits;
+    int min_shift;  // tests: a rank at least this coarse, whatever the frame's depth span
     __host__ __device__ uint32_t idx_mask() const { return idx_bits >= 32 ? 0xffffffffu : (1u << idx_bits) - 1u; }
     __host__ __device__ int shift(uint32_t dmin, uint32_t dmax) const
     {
         const uint32_t span = dmax > dmin ? dmax - dmin : 0u;
         const int len = span ? 32 - __builtin_clz(span) : 0;  // bit length of the span
-        return len > key_bits + word_bits ? len - (key_bits + word_bits) : 0;
+        const int sh = len > key_bits + word_bits ? len - (key_bits + word_bits) : 0;
+        return sh > min_shift ? sh : min_shift;
     }
     // the rank of a depth, and its two parts as they are stored
     __host__ __device__ uint32_t rank(uint32_t bits, uint32_t dmin, int sh) const
@@ -148,7 +150,7 @@ struct DepthRank {
 // P Gaussians, tile ids of tile_bits bits.  The rank is at most 31 bits long (the span of positive floats).
 static inline DepthRank ngs_depth_rank(int P, int tile_bits, bool wanted)
 {
-    DepthRank d = {0, 0, 32};
+    DepthRank d = {0, 0, 32, 0};
     if (!wanted || 32 - tile_bits < 12) return d;
     d.key_bits = 32 - tile_bits;
     if (d.key_bits > 31) d.key_bits = 31;

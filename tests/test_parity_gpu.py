@@ -31,12 +31,14 @@ def dgr():
     return m
 
 
-@pytest.fixture(params=["by_tile", "by_gaussian"])
+@pytest.fixture(params=["by_tile", "by_gaussian", "by_tile_coarse_rank", "by_tile_no_rank"])
 def depth_order(request, dgr):
-    """Runs a test once per way of obtaining the depth order of the tile lists (a per-tile sort of the instances,
-    or a sort of the Gaussians before their instances are emitted); left alone, the library picks one per call."""
+    """Runs a test once per way of obtaining the depth order of the tile lists: a per-tile sort of the instances
+    (keyed by the depth rank the instances carry; with that rank too coarse to be used, so that depths are fetched
+    after all; with no rank carried), or a sort of the Gaussians before their instances are emitted.  Left alone,
+    the library picks one per call."""
     L = dgr._lib.lib()
-    L.ngs_debug_depth_order(0 if request.param == "by_tile" else 1)
+    L.ngs_debug_depth_order({"by_tile": 0, "by_gaussian": 1, "by_tile_coarse_rank": 2, "by_tile_no_rank": 3}[request.param])
     yield request.param
     L.ngs_debug_depth_order(-1)
 
