@@ -182,7 +182,11 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         const float4* row = (const float4*)(acc + i * NGS_ACC_STRIDE);
         const float4 r0 = row[0], r1 = row[1];
         const float r2 = acc[i * NGS_ACC_STRIDE + 8];
-        g_dx = r0.x; g_dy = r0.y; g_ca = r0.z; g_cb = r0.w; g_cc = r1.x; g_op = r1.y;
+        // The compositing pass leaves, per Gaussian, the moments of dL/dG over the pixel offsets d it was blended at:
+        // m1 = sum dL/dG G d (r0.x, r0.y) and m2 = sum dL/dG G (dx^2, dx dy, dy^2) (r0.z, r0.w, r1.x); the conic that
+        // turns them into the gradients of backward.cu:545-551 is the same for every pixel and is applied below.
+        const float m1x = r0.x, m1y = r0.y;
+        g_ca = -0.5f * r0.z; g_cb = -0.5f * r0.w; g_cc = -0.5f * r1.x; g_op = r1.y;
         g_col = make_float3(r1.z, r1.w, r2);
 
         float c6[6];
@@ -199,6 +203,12 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_bwd_kernel(
         const float ymul = (k.tytz < -k.limy || k.tytz > k.limy) ? 0.f : 1.f;
         const float a = k.a, b = k.b, c = k.c;
         const float denom = a * c - b * b;
+        {   // the conic as the forward pass formed it (forward.cu:219-222); a visible Gaussian has denom != 0
+            const float dinv = 1.f / denom;
+            const float con_x = c * dinv, con_y = -b * dinv, con_z = a * dinv;
+            g_dx = -(con_x * m1x + con_y * m1y) * (float)(0.5 * cam.W);
+            g_dy = -(con_y * m1x + con_z * m1y) * (float)(0.5 * cam.H);
+        }
         float dL_da = 0, dL_db = 0, dL_dc = 0;
         const float d2inv = 1.0f / ((denom * denom) + 0.0000001f);
         const Mat3& T = k.T;

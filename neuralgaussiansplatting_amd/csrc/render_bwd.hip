@@ -45,7 +45,7 @@ __device__ __forceinline__ float row_pair_sum(float a)
 #define DPP_QUAD_XOR2 0x4E         // quad_perm [2,3,0,1]
 #define DPP_QUAD_XOR1 0xB1         // quad_perm [1,0,3,2]
 
-#define BWD_BATCH NGS_TILE_PIX  // splats staged per round
+#define BWD_BATCH 128  // splats staged per round
 
 #ifdef NGS_BWD_STATS
 // Diagnostic build: utilisation counters of the walk.  [0] wave-steps, [1] row-steps with an entry, [2] live
@@ -70,7 +70,11 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
 {
     // record k: [0] = {x, y, ln(255 opacity), -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
     __shared__ float4 s_rec[BWD_BATCH][3];
-    __shared__ float s_acc[BWD_BATCH][ACC_USED];
+    // One table of sums per wave: a wave's LDS operations complete in order, so it adds to its own table with a plain
+    // read, add and write (an LDS float atomic costs about three cycles of the CU's LDS per active lane, ten times
+    // an integer one or a store).  In the steps where several of its rows work on the same splat the rows pool their
+    // sums first and one of them writes.
+    __shared__ float s_acc[NGS_TILE_PIX / 64][BWD_BATCH][ACC_USED];
     __shared__ uint8_t s_list[NGS_TILE_PIX / 64][4][BWD_BATCH];  // per wave and quadrant: staged slots to visit
     __shared__ uint32_t s_wmax[NGS_TILE_PIX / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,10 +118,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     bgdot += bg[0] * dpr;
     bgdot += bg[1] * dpg;
     bgdot += bg[2] * dpb;
+    const float bg_term = -T_final * bgdot;  // d(background's share of the pixel)/d(alpha) is this over (1 - alpha)
     v2f rec_rg = {0.0f, 0.0f};
     float rec_b = 0.0f;
     const v2f dp_rg = {dpr, dpg};
-    const v2f ddel = {(float)(0.5 * W), (float)(0.5 * H)};  // d(pixel offset)/d(ndc)
     // After the reduce-scatter the even lanes of a row hold partials 0..7 (index bits taken from lane bits 3, 2, 1
     // in that order of significance 1, 2, 4) and the odd lanes partial 8; lane 1 speaks for the odd ones.
     const bool up8 = (li & 8) != 0, up4 = (li & 4) != 0, up2 = (li & 2) != 0, up1 = (li & 1) != 0;
@@ -145,8 +149,11 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             s_rec[tid][1] = make_float4(a.z, a.w, b.x, b.y);
             s_rec[tid][2] = make_float4(b.z, b.w, c, __uint_as_float(id));
         }
+        static_assert(sizeof(s_acc) % sizeof(float4) == 0, "the tables are cleared with 16-byte stores");
 #pragma unroll
-        for (int c = 0; c < ACC_USED; c++) s_acc[tid][c] = 0.0f;
+        for (int c = 0; c * NGS_TILE_PIX < (int)(sizeof(s_acc) / sizeof(float4)); c++)
+            if (c * NGS_TILE_PIX + tid < (int)(sizeof(s_acc) / sizeof(float4)))
+                ((float4*)&s_acc[0][0][0])[c * NGS_TILE_PIX + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
 
         // ---- which staged splats does each quadrant of this block have to visit? ----
@@ -180,18 +187,30 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int my_n = row == 0 ? n0 : row == 1 ? n1 : row == 2 ? n2 : n3;
         const int steps = max(max(n0, n1), max(n2, n3));
+        // Steps in which two rows of this wave work on the same splat (their sums then meet in one table entry): one
+        // bit per step, found 64 steps at a time.
+        unsigned long long dup[BWD_BATCH / 64];
+#pragma unroll
+        for (int ch = 0; ch < BWD_BATCH / 64; ch++) {
+            dup[ch] = 0ull;
+            if (ch * 64 < steps) {  // wave-uniform
+                const int t = ch * 64 + lane;
+                const int e0 = t < n0 ? (int)s_list[wave][0][t] : -1, e1 = t < n1 ? (int)s_list[wave][1][t] : -2;
+                const int e2 = t < n2 ? (int)s_list[wave][2][t] : -3, e3 = t < n3 ? (int)s_list[wave][3][t] : -4;
+                dup[ch] = wave_mask(e0 == e1 || e0 == e2 || e0 == e3 || e1 == e2 || e1 == e3 || e2 == e3);
+            }
+        }
 
         // ---- the four rows walk their lists side by side ----
         // Slot addresses as 24-bit multiply-adds: the 48- and 36-byte strides would otherwise cost a quarter-rate
         // 32/64-bit integer multiply each, twice per step.
         const char* const rec_bytes = (const char*)&s_rec[0][0];
-        char* const acc_lane = (char*)&s_acc[0][0] + 4 * max(my_slot, 0);
+        char* const acc_lane = (char*)&s_acc[wave][0][0] + 4 * max(my_slot, 0);
         // One step of a row: splat `j` of the batch (record p, q, col) against the row's 16 pixels.
-        auto step = [&](const int it, const int j, const float4 p, const float4 q, const float4 col) {
+        auto step = [&](const int it, const int j, const float4 p, const float4 q, const float4 col, const bool shared) {
             const bool have = it < my_n;
             const uint32_t pos = (uint32_t)(first - j);  // the reference's `contributor` after its decrement
             const float dx = p.x - pxf, dy = p.y - pyf;
-            const v2f d = {dx, dy};
             // same evaluation order as the forward pass (and the reference): alpha must come out bit-identical
             const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
             const float G = exp_nonpos(power);
@@ -209,6 +228,9 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             // alpha = 0, which leaves its state untouched without a single select: T / (1 - 0) = T, the
             // colour behind it becomes 0 * colour + 1 * rec = rec, and every partial below is an exact zero
             // (G and dL/dalpha are forced to 0 as well).
+            // the table entry this lane will add to, on its way while the sums are formed
+            float* const entry = (float*)(acc_lane + __umul24((unsigned)j, (unsigned)sizeof(float[ACC_USED])));
+            const float before = *(volatile float*)entry;
             const float alpha_l = live ? alpha : 0.0f;
             const float om = 1.f - alpha_l;
             const float inv = __builtin_amdgcn_rcpf(om);  // v_rcp_f32, 1 ulp; exactly 1 for a dead lane
@@ -221,21 +243,16 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             // fixed order anyway): products and sums are fused where that saves an instruction.
             const v2f d_rg = col_rg - rec_rg;
             float dL_dalpha = fmaf(col.z - rec_b, dpb, fmaf(d_rg.y, dp_rg.y, d_rg.x * dp_rg.x));
-            dL_dalpha = fmaf(dL_dalpha, Tn, (-T_final * inv) * bgdot);
-            dL_dalpha = live ? dL_dalpha : 0.0f;
-            const float Gl = live ? G : 0.0f;
-            const float dL_dG = q.w * dL_dalpha;
-            const v2f gd = Gl * d;  // {G dx, G dy}
-            const v2f gx = {gd.x, gd.x}, gy = {gd.y, gd.y};
-            // {dG/ddelx, dG/ddely} = -gdx * {a, b} - gdy * {b, c}
-            const v2f dG = -__builtin_elementwise_fma(gy, (v2f){q.y, q.z}, gx * (v2f){q.x, q.y});
-            const v2f v01 = (dL_dG * dG) * ddel;            // ACC_DX, ACC_DY
-            const v2f h = -0.5f * gd;
-            const v2f v23 = ((v2f){h.x, h.x} * d) * dL_dG;  // ACC_CON_A, ACC_CON_B
-            const float v4 = h.y * dy * dL_dG;              // ACC_CON_C
-            const float v5 = Gl * dL_dalpha;                // ACC_OPAC
-            const v2f v67 = w * dp_rg;                      // ACC_R, ACC_G
-            const float v8 = w * dpb;                       // ACC_B
+            dL_dalpha = fmaf(dL_dalpha, Tn, bg_term * inv);
+            // What leaves the pixel are the moments of g = G dL/dalpha over the pixel offsets: the splat's conic and
+            // opacity, which turn them into the gradients of its position, conic and opacity, are the same for every
+            // pixel and are applied once per splat when the batch is flushed.
+            const float g = live ? G * dL_dalpha : 0.0f;
+            const float go = q.w * g;  // dL/dG
+            const float m1x = go * dx, m1y = go * dy;
+            const float m2xx = m1x * dx, m2xy = m1x * dy, m2yy = m1y * dy;
+            const v2f v67 = w * dp_rg;  // ACC_R, ACC_G
+            const float v8 = w * dpb;   // ACC_B
             // state for the next (nearer) splat: transmittance in front of this one, and the colour behind
             // the next one = this splat blended over what was behind it (same expression the reference
             // evaluates one step later from its last_alpha / last_color)
@@ -244,9 +261,9 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             rec_b = fmaf(alpha_l, col.z, om * rec_b);
 
             // Sum over the quadrant's 16 pixels: four exchange steps, each halving the number of registers.
-            const float a01 = row_fold<DPP_ROW_MIRROR>(v01.x, v01.y, up8);
-            const float a23 = row_fold<DPP_ROW_MIRROR>(v23.x, v23.y, up8);
-            const float a45 = row_fold<DPP_ROW_MIRROR>(v4, v5, up8);
+            const float a01 = row_fold<DPP_ROW_MIRROR>(m1x, m1y, up8);
+            const float a23 = row_fold<DPP_ROW_MIRROR>(m2xx, m2xy, up8);
+            const float a45 = row_fold<DPP_ROW_MIRROR>(m2yy, g, up8);
             const float a67 = row_fold<DPP_ROW_MIRROR>(v67.x, v67.y, up8);
             const float a8 = row_pair_sum<DPP_ROW_MIRROR>(v8);
             const float b03 = row_fold<DPP_ROW_HALF_MIRROR>(a01, a23, up4);
@@ -255,8 +272,22 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             const float c07 = row_fold<DPP_QUAD_XOR2>(b03, b47, up2);
             const float c8 = row_pair_sum<DPP_QUAD_XOR2>(b8);
             const float total = row_fold<DPP_QUAD_XOR1>(c07, c8, up1);
-            if (have && my_slot >= 0 && total != 0.0f)
-                atomicAdd((float*)(acc_lane + __umul24((unsigned)j, (unsigned)sizeof(float[ACC_USED]))), total);
+            float sum = total;
+            bool mine = have && my_slot >= 0;
+            if (shared) {  // wave-uniform
+                // Rows that work on the same splat in this step pool their sums, and the first of them writes.
+                const int key = have ? j : -1 - row;  // a row without an entry matches nobody
+#pragma unroll
+                for (int o = 16; o < 64; o += 16) {
+                    const int other_key = __shfl_xor(key, o, 64);
+                    const float other = __shfl_xor(total, o, 64);
+                    if (other_key == key) {
+                        sum += other;
+                        if ((row ^ (o >> 4)) < row) mine = false;
+                    }
+                }
+            }
+            if (mine) *(volatile float*)entry = before + sum;
         };
         auto record_of = [&](const int j) {
             return (const float4*)(rec_bytes + __umul24((unsigned)j, (unsigned)sizeof(float4[3])));
@@ -273,12 +304,12 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             const float4* rb = record_of(jb);
             const float4 pb = rb[0], qb = rb[1], cb = rb[2];
             const int jc = list_at(it + 2);
-            step(it, ja, pa, qa, ca);
+            step(it, ja, pa, qa, ca, (dup[(it >> 6) & (BWD_BATCH / 64 - 1)] >> (it & 63)) & 1ull);
             if (it + 1 >= steps) break;
             ra = record_of(jc);
             pa = ra[0]; qa = ra[1]; ca = ra[2];
             const int jd = list_at(it + 3);
-            step(it + 1, jb, pb, qb, cb);
+            step(it + 1, jb, pb, qb, cb, (dup[((it + 1) >> 6) & (BWD_BATCH / 64 - 1)] >> ((it + 1) & 63)) & 1ull);
             ja = jc;
             jb = jd;
         }
@@ -295,10 +326,12 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
         }
 #endif
         // Flush: 16 lanes per splat, lane c adds slot c of the splat's 64-byte accumulator row.
+        // Flush: 16 lanes per splat, lane c adds slot c of the splat's 64-byte accumulator row (the four waves'
+        // tables summed).
         const int c = tid & 15;
         for (int j = tid >> 4; j < nb; j += NGS_TILE_PIX / 16) {
             if (c < ACC_USED) {
-                const float v = s_acc[j][c];
+                const float v = (s_acc[0][j][c] + s_acc[1][j][c]) + (s_acc[2][j][c] + s_acc[3][j][c]);
                 if (v != 0.0f)
                     atomicAdd(acc + (size_t)__float_as_uint(s_rec[j][2].w) * NGS_ACC_STRIDE + c, v);
             }
