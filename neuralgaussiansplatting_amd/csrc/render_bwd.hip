@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
         // Slot addresses as 24-bit multiply-adds: the 48- and 36-byte strides would otherwise cost a quarter-rate
         // 32/64-bit integer multiply each, twice per step.
         const char* const rec_bytes = (const char*)&s_rec[0][0];
-        char* const acc_lane = (char*)&s_acc[wave][0][0] + 4 * max(my_slot, 0);
+        float* const acc_lane = &s_acc[wave][0][0] + max(my_slot, 0);
         // One step of a row: splat `j` of the batch (record p, q, col) against the row's 16 pixels.
         auto step = [&](const int it, const int j, const float4 p, const float4 q, const float4 col, const bool shared) {
             const bool have = it < my_n;
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             // colour behind it becomes 0 * colour + 1 * rec = rec, and every partial below is an exact zero
             // (G and dL/dalpha are forced to 0 as well).
             // the table entry this lane will add to, on its way while the sums are formed
-            float* const entry = (float*)(acc_lane + __umul24((unsigned)j, (unsigned)sizeof(float[ACC_USED])));
-            const float before = *(volatile float*)entry;
+            float* const entry = acc_lane + __umul24((unsigned)j, (unsigned)ACC_USED);
+            const float before = *entry;
             const float alpha_l = live ? alpha : 0.0f;
             const float om = 1.f - alpha_l;
             const float inv = __builtin_amdgcn_rcpf(om);  // v_rcp_f32, 1 ulp; exactly 1 for a dead lane
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
                     }
                 }
             }
-            if (mine) *(volatile float*)entry = before + sum;
+            if (mine) *entry = before + sum;
         };
         auto record_of = [&](const int j) {
             return (const float4*)(rec_bytes + __umul24((unsigned)j, (unsigned)sizeof(float4[3])));
