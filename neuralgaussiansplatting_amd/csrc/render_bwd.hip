@@ -71,9 +71,9 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     // record k: [0] = {x, y, ln(255 opacity), -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
     __shared__ float4 s_rec[BWD_BATCH][3];
     // One table of sums per wave: a wave's LDS operations complete in order, so it adds to its own table with a plain
-    // read, add and write (an LDS float atomic costs about three cycles of the CU's LDS per active lane, ten times
-    // an integer one or a store).  In the steps where several of its rows work on the same splat the rows pool their
-    // sums first and one of them writes.
+    // read, add and write.  An LDS float atomic costs about three cycles of the CU's LDS per active lane, ten times
+    // an integer one or a store (tools/probes/lds_atomic_probe.hip); it is kept for the steps in which several rows
+    // of the wave work on the same splat and so meet in one entry.
     __shared__ float s_acc[NGS_TILE_PIX / 64][BWD_BATCH][ACC_USED];
     __shared__ uint8_t s_list[NGS_TILE_PIX / 64][4][BWD_BATCH];  // per wave and quadrant: staged slots to visit
     __shared__ uint32_t s_wmax[NGS_TILE_PIX / 64];
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             // the table entry this lane will add to, on its way while the sums are formed
             float* const entry = acc_lane + __umul24((unsigned)j, (unsigned)ACC_USED);
             const float before = *entry;
+            asm volatile("" :: "v"(col.w));  // the colour comes as one 16-byte LDS read (a 12-byte one costs twice the LDS cycles)
             const float alpha_l = live ? alpha : 0.0f;
             const float om = 1.f - alpha_l;
             const float inv = __builtin_amdgcn_rcpf(om);  // v_rcp_f32, 1 ulp; exactly 1 for a dead lane
@@ -272,22 +273,13 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             const float c07 = row_fold<DPP_QUAD_XOR2>(b03, b47, up2);
             const float c8 = row_pair_sum<DPP_QUAD_XOR2>(b8);
             const float total = row_fold<DPP_QUAD_XOR1>(c07, c8, up1);
-            float sum = total;
-            bool mine = have && my_slot >= 0;
-            if (shared) {  // wave-uniform
-                // Rows that work on the same splat in this step pool their sums, and the first of them writes.
-                const int key = have ? j : -1 - row;  // a row without an entry matches nobody
-#pragma unroll
-                for (int o = 16; o < 64; o += 16) {
-                    const int other_key = __shfl_xor(key, o, 64);
-                    const float other = __shfl_xor(total, o, 64);
-                    if (other_key == key) {
-                        sum += other;
-                        if ((row ^ (o >> 4)) < row) mine = false;
-                    }
+            if (have && my_slot >= 0) {
+                if (shared) {  // wave-uniform: rows that work on the same splat in this step meet in one entry
+                    if (total != 0.0f) atomicAdd(entry, total);
+                } else {
+                    *entry = before + total;
                 }
             }
-            if (mine) *entry = before + sum;
         };
         auto record_of = [&](const int j) {
             return (const float4*)(rec_bytes + __umul24((unsigned)j, (unsigned)sizeof(float4[3])));
