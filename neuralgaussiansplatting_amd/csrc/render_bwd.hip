@@ -103,6 +103,11 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     const uint32_t qmax3 = (uint32_t)__builtin_amdgcn_readlane((int)qmax, 48);
     const uint32_t wmax = max(max(qmax0, qmax1), max(qmax2, qmax3));
     if (lane == 0) s_wmax[wave] = wmax;
+    // The walk reads list entries, and the records they name, one and two steps ahead of knowing whether they exist:
+    // whatever it can come across must be a valid slot number and a finite record (a row without an entry runs the
+    // arithmetic with alpha = 0, which leaves its state alone only if the colour it multiplies by 0 is finite).
+    for (int k = tid; k < (int)(sizeof(s_list) / sizeof(uint32_t)); k += NGS_TILE_PIX) ((uint32_t*)&s_list[0][0][0])[k] = 0u;
+    for (int k = tid; k < BWD_BATCH * 3; k += NGS_TILE_PIX) (&s_rec[0][0])[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     const uint32_t tmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     if (tmax == 0) return;  // nothing in this tile was blended (block-uniform)
