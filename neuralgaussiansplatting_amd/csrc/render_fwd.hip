@@ -73,14 +73,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
             }
         }
         unsigned long long mask = wave_mask(reach);
-        int visits = 0;
-        while (mask) {
-            const int j = lowest_lane(mask);
-            mask &= mask - 1ull;
-            const float4 p = rec[j][0];
-            const float4 q = rec[j][1];
-            const float4 col = rec[j][2];
-            asm volatile("" ::"v"(col.w));  // one 16-byte LDS read (a 12-byte one costs twice the LDS cycles)
+        // One splat against the wave's 64 pixels.
+        auto visit = [&](const int j, const float4 p, const float4 q, const float4 col) {
             const float dx = p.x - pxf, dy = p.y - pyf;
             const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
             const float alpha = fminf(0.99f, q.w * exp_nonpos(power));
@@ -98,8 +92,22 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
             Cb = fmaf(col.z * alpha_b, T, Cb);
             T = blend ? test_T : T;
             last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
-            // every fourth visit: has the whole block saturated?  (a saturated pixel ignores further splats anyway)
-            if ((++visits & 3) == 0 && wave_mask(!done) == 0ull) break;
+        };
+        // Two surviving splats per trip: both records are requested before the first is used, so the second's LDS
+        // latency passes behind the first's arithmetic, and the loop's scalar bookkeeping is paid once per pair.
+        while (mask) {
+            const int j0 = lowest_lane(mask);
+            mask &= mask - 1ull;
+            const bool pair = mask != 0ull;
+            const int j1 = pair ? lowest_lane(mask) : j0;
+            mask &= mask - 1ull;  // 0 stays 0
+            const float4 p0 = rec[j0][0], q0 = rec[j0][1], c0 = rec[j0][2];
+            const float4 p1 = rec[j1][0], q1 = rec[j1][1], c1 = rec[j1][2];
+            asm volatile("" ::"v"(c0.w), "v"(c1.w));  // 16-byte LDS reads (a 12-byte one costs twice the LDS cycles)
+            visit(j0, p0, q0, c0);
+            if (pair) visit(j1, p1, q1, c1);
+            // has the whole block saturated?  (a saturated pixel ignores further splats anyway)
+            if (wave_mask(!done) == 0ull) break;
         }
     }
     if (inside) {
