@@ -53,12 +53,14 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
         "duplicate_with_keys": 4 * P + 12 * vP + 8 * R,
         "radix_sort_tile_bits": tile_passes * 16 * R,
         "tile_ranges": 4 * R + 16 * T,
-        "segment_sort_depth": 4 * R + 4 * R + 4 * R + 8 * T,  # list in, depth gather, list out
+        # list words and keys in (both carry the depth rank, so no depth is gathered), list out
+        "segment_sort_depth": 4 * R + 4 * R + 4 * R + 8 * T,
         # four 8-bit passes over P (depth bits, index) pairs (histogram read + pair read + pair write), then the
         # gather of tile counts and rectangles into depth order
         "depth_sort_gaussians": 4 * (4 + 8 + 8) * P + (4 + 4 + 8 + 12) * P,
-        "render_fwd": 40 * R + 8 * T + 20 * W * H,
-        "zero_accumulator": 64 * P,
+        # the compositing kernel also clears the backward pass's accumulator rows (64 bytes per Gaussian)
+        "render_fwd": 40 * R + 8 * T + 20 * W * H + 64 * P,
+        "zero_accumulator": 4,  # a flag read: the rows are clear already
         "render_bwd": 112 * R + 8 * T + 20 * W * H,
         "preprocess_bwd": 4 * P + vP * (105 + 12 * c) + P * (92 + 12 * M),
         # training-step companions: per iteration (the Adam stages are several launches)

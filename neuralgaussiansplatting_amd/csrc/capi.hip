@@ -419,7 +419,7 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         }
         prof_begin(ps, ST_RENDER_FWD, st);
         ngs_launch_render_fwd(st, cam, ranges, vals[0], rec, background, (float*)(ib + il.final_T),
-                              (uint32_t*)(ib + il.n_contrib), out_color);
+                              (uint32_t*)(ib + il.n_contrib), out_color, (float*)(gb + gl.acc), P, misc);
         prof_end(ps, ST_RENDER_FWD, st);
         NGS_STAGE("render");
         if (count_known) break;
@@ -530,13 +530,14 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
 
     const int ps = prof_acquire();
     prof_begin(ps, ST_BWD_ZERO, st);
-    NGS_HIP(hipMemsetAsync(acc, 0, (size_t)P * NGS_ACC_STRIDE * sizeof(float), st));
+    uint32_t* misc = (uint32_t*)(gb + gl.misc);
+    ngs_launch_zero_acc_unless_clean(st, acc, P, misc);  // normally nothing to do: the forward pass left them clear
     prof_end(ps, ST_BWD_ZERO, st);
     prof_begin(ps, ST_RENDER_BWD, st);
     ngs_launch_render_bwd(st, cam, (const uint2*)(ib + il.ranges), (const uint32_t*)(bb + bl.vals[0]),
                           (const float4*)(gb + gl.rec),
                           background, (const float*)(ib + il.final_T), (const uint32_t*)(ib + il.n_contrib), dL_dpix,
-                          acc);
+                          acc, misc);
     prof_end(ps, ST_RENDER_BWD, st);
     NGS_STAGE("render backward");
     if (early && early->out) {

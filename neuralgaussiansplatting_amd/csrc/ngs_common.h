@@ -19,6 +19,7 @@
 // Slots of one accumulator row filled by the backward compositing kernel.
 #define NGS_MISC_DMIN 2
 #define NGS_MISC_DMAX 3
+#define NGS_MISC_ACC_CLEAN 4  // 1: the gradient accumulator rows are all zero (the forward pass left them so)
 enum { ACC_DX = 0, ACC_DY, ACC_CON_A, ACC_CON_B, ACC_CON_C, ACC_OPAC, ACC_R, ACC_G, ACC_B, ACC_USED };
 
 // ---------------------------------------------------------------------------
@@ -41,7 +42,7 @@ struct GeomLayout {
     size_t misc;       // u32   [8]  [0] total instances R, [1] error flags (1 prefiltered point culled, 2 count
                        //            beyond 2^31-1, 4 count beyond the binning buffer's capacity), [2] / [3] a lower /
                        //            upper bound of the depth bits of the visible Gaussians, within 2^16 of the extremes
-                       //            (0xffff0000 / 0 when there is none)
+                       //            (0xffff0000 / 0 when there is none), [4] 1 while the accumulator rows are all zero
     size_t acc;        // float [P][16] gradient accumulator rows (backward)
     // Depth order of the Gaussians (forward only): instances are emitted in this order, so that the stable
     // tile-level sort leaves every tile's list sorted by depth.
@@ -315,13 +316,18 @@ void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t cap
 void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
                               uint32_t* const vals[2], uint32_t* hard, const DepthRank& dr, const uint32_t* misc);
 // render_fwd.hip
+// acc / P / misc: the compositing kernel also clears the P gradient accumulator rows for the backward pass (it is
+// bound by arithmetic and leaves the memory system idle) and says so in misc[NGS_MISC_ACC_CLEAN].
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,
-                           uint32_t* n_contrib, float* out_color);
+                           uint32_t* n_contrib, float* out_color, float* acc, int P, uint32_t* misc);
 // render_bwd.hip
+// Clears the accumulator rows unless misc[NGS_MISC_ACC_CLEAN] says they are clear already.
+void ngs_launch_zero_acc_unless_clean(hipStream_t s, float* acc, int P, const uint32_t* misc);
+// misc: the kernel marks the accumulator rows as used (misc[NGS_MISC_ACC_CLEAN] = 0).
 void ngs_launch_render_bwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, const float* final_T,
-                           const uint32_t* n_contrib, const float* dL_dpix, float* acc);
+                           const uint32_t* n_contrib, const float* dL_dpix, float* acc, uint32_t* misc);
 // preprocess_bwd.hip
 // opac_raw != NULL: scales, rots and opac_raw are the optimiser's raw parameters (the kernel applies exp /
 // normalise / sigmoid itself) and the three gradients come out wrt those raw values.  geo (needs raw parameters):

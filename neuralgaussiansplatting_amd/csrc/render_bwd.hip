@@ -66,8 +66,9 @@ extern "C" int ngs_debug_bwd_stats(unsigned long long* out)
 __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
     const float4* __restrict__ splat_rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dpix, float* __restrict__ acc)
+    const float* __restrict__ dL_dpix, float* __restrict__ acc, uint32_t* __restrict__ misc)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) misc[NGS_MISC_ACC_CLEAN] = 0u;  // the rows are about to be used
     // record k: [0] = {x, y, ln(255 opacity), -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
     __shared__ float4 s_rec[BWD_BATCH][3];
     // One table of sums per wave: a wave's LDS operations complete in order, so it adds to its own table with a plain
@@ -343,8 +344,27 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
 
 void ngs_launch_render_bwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, const float* final_T,
-                           const uint32_t* n_contrib, const float* dL_dpix, float* acc)
+                           const uint32_t* n_contrib, const float* dL_dpix, float* acc, uint32_t* misc)
 {
     hipLaunchKernelGGL(render_bwd_kernel, dim3(cam.grid_x * cam.grid_y), dim3(NGS_TILE_PIX), 0, s, cam.W, cam.H,
-                       cam.grid_x, ranges, plist, rec, bg, final_T, n_contrib, dL_dpix, acc);
+                       cam.grid_x, ranges, plist, rec, bg, final_T, n_contrib, dL_dpix, acc, misc);
+}
+
+// The forward pass leaves the accumulator rows cleared and says so in misc[NGS_MISC_ACC_CLEAN]; a second backward
+// pass over the same state finds the word at 0 and clears them itself.
+__global__ __launch_bounds__(256) void zero_acc_unless_clean_kernel(float* __restrict__ acc, long long n_f4,
+                                                                    const uint32_t* __restrict__ misc)
+{
+    if (misc[NGS_MISC_ACC_CLEAN] == 1u) return;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_f4; i += (long long)gridDim.x * 256)
+        stream_store4(acc + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+void ngs_launch_zero_acc_unless_clean(hipStream_t s, float* acc, int P, const uint32_t* misc)
+{
+    const long long n_f4 = (long long)P * (NGS_ACC_STRIDE / 4);
+    // a small grid: the launch normally finds nothing to do, and the rare launch that does can take its time
+    const long long blocks = (n_f4 + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(zero_acc_unless_clean_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, s,
+                       acc, n_f4, misc);
 }

@@ -20,13 +20,21 @@
 __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
     const float4* __restrict__ rec_g, const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ out_color)
+    float* __restrict__ out_color, float* __restrict__ acc, int acc_f4_per_block, int acc_f4_total,
+    uint32_t* __restrict__ misc)
 {
     // per wave, record k: [0] = {x, y, -, -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, -}; 64-byte slots, so
     // the address of slot k is a shift-and-add (a 48-byte stride costs a quarter-rate 64-bit multiply-add per visit)
     __shared__ float4 s_rec[NGS_TILE_PIX / 64][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
+    // This workgroup's share of the backward pass's accumulator rows is cleared here: the stores leave at once and
+    // complete behind the compositing, which keeps the vector ALU busy and the memory system idle.
+    {
+        const int lo = tile * acc_f4_per_block, hi = min(acc_f4_total, lo + acc_f4_per_block);
+        for (int i = lo + tid; i < hi; i += NGS_TILE_PIX) stream_store4(acc + 4 * (size_t)i, make_float4(0.f, 0.f, 0.f, 0.f));
+        if (tile == 0 && tid == 0) misc[NGS_MISC_ACC_CLEAN] = 1u;
+    }
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int px = tx * NGS_TILE_W + tile_local_x(tid), py = ty * NGS_TILE_H + tile_local_y(tid);
     const bool inside = px < W && py < H;
@@ -123,8 +131,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
 
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,
-                           uint32_t* n_contrib, float* out_color)
+                           uint32_t* n_contrib, float* out_color, float* acc, int P, uint32_t* misc)
 {
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(cam.grid_x * cam.grid_y), dim3(NGS_TILE_PIX), 0, s, cam.W, cam.H,
-                       cam.grid_x, ranges, plist, rec, bg, final_T, n_contrib, out_color);
+    const int T = cam.grid_x * cam.grid_y;
+    const long long f4 = (long long)P * (NGS_ACC_STRIDE / 4);  // P <= NGS_MAX_GAUSSIANS keeps this inside an int
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(NGS_TILE_PIX), 0, s, cam.W, cam.H, cam.grid_x, ranges, plist,
+                       rec, bg, final_T, n_contrib, out_color, acc, (int)((f4 + T - 1) / T), (int)f4, misc);
 }

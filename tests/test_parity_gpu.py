@@ -837,3 +837,30 @@ def test_factored_exchange_over_rccl_single_rank(dgr):
     ret = mgr.dict()
     mp.spawn(_rccl_single_rank_worker, args=(33500 + os.getpid() % 2000, ret), nprocs=1, join=True)
     assert dict(ret) == {0: True}
+
+
+@pytest.mark.gpu
+def test_second_backward_over_the_same_state(dgr):
+    """The forward pass leaves the gradient accumulator rows cleared for the backward pass; a second backward pass
+    over the same saved state (retain_graph) has to clear them itself and must give the same gradients."""
+    from neuralgaussiansplatting_amd.gaussian_model import GaussianModel
+    from neuralgaussiansplatting_amd.gaussian_renderer import PipelineParams, render
+    from neuralgaussiansplatting_amd.cameras import make_camera
+    from neuralgaussiansplatting_amd import synthetic
+    dev = torch.device("cuda:0")
+    c = case(P=3000, W=96, H=80, D=3, M=16, seed=43)
+    sc = c["scene"]
+    cam_d = make_camera(96, 80, synthetic.FOVX, (0.7, 0.5, -4.0), device=dev)
+    model = GaussianModel.from_activated(sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations, sh_degree=3,
+                                         active_sh_degree=3, device=dev)
+    dL = torch.randn(3, 80, 96, generator=torch.Generator().manual_seed(8)).to(dev)
+    pkg = render(cam_d, model, PipelineParams(), c["bg"].to(dev))
+    loss = (pkg["render"] * dL).sum()
+    params = [model._xyz, model._features_dc, model._features_rest, model._opacity, model._scaling, model._rotation]
+    first = [g.clone() for g in torch.autograd.grad(loss, params, retain_graph=True)]
+    for _ in range(2):
+        again = torch.autograd.grad(loss, params, retain_graph=True)
+        for a, b in zip(first, again):
+            assert torch.isfinite(b).all()
+            # the sums are formed by float atomics in an order that differs from run to run
+            assert (a - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
