@@ -50,7 +50,7 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
         "preprocess_fwd": P * (12 + 8) + vP * (32 + 12 * c + 49),
         "scan_block_sums": 8 * ((P + 255) // 256),
         # the tile-level sort moves (tile id, Gaussian index) pairs of 8 bytes; the depth joins in the per-tile sort
-        "duplicate_with_keys": 4 * P + 12 * vP + 8 * R,
+        "duplicate_with_keys": 4 * P + 16 * vP + 8 * R,  # tile count; rectangle, offset share and depth; key + list word
         "radix_sort_tile_bits": tile_passes * 16 * R,
         "tile_ranges": 4 * R + 16 * T,
         # list words and keys in (both carry the depth rank, so no depth is gathered), list out
@@ -374,15 +374,17 @@ def main():
                     fname, src.get("raw", "rocprofv3 --pmc passes"), src.get("commit", "unrecorded"), here)
 
             traffic, traffic_source = profiled("hbm_traffic.json")
-            # the compositing kernels are limited by vector-ALU issue, not by HBM: quote the counter-derived issue
-            # fraction (share of the one-wave64-FP32-instruction-per-2-cycles peak) as well
+            # the compositing kernels are limited by vector-ALU issue and LDS, not by HBM: quote the counter-derived
+            # issue fraction as well (share of a nominal peak of one wave64 FP32 instruction per 2 cycles per SIMD;
+            # no kernel here has been seen above 0.55 of it, see tools/pmc_valu_summary.py)
             valu, valu_source = profiled("valu_issue.json")
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "traffic_source": traffic_source, "avg_launch_ms": round(dom_ms, 4),
                         "algorithmic_bytes": int(nbytes[dom]), "valu_issue_frac": valu, "valu_source": valu_source,
-                        "limiter": "vector-ALU issue (valu_issue_frac), not HBM: the kernel moves less than its "
-                                   "algorithmic bytes" if dom.startswith("render_") else "HBM"}
+                        "limiter": "vector-ALU issue (valu_issue_frac; the practical ceiling is about 0.55) and LDS, "
+                                   "not HBM: the kernel moves less than its algorithmic bytes"
+                                   if dom.startswith("render_") else "HBM"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene_cpu, synthetic.make_view(W, H, index=0, count=8), W, H, D, tanx, tany, dL)

@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
-"""Vector-ALU load of each kernel from one rocprofv3 --pmc pass over
-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE.
+"""Vector-ALU and LDS load of each kernel from one rocprofv3 --pmc pass over
+SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE.
 
     python tools/pmc_valu_summary.py gpurun_out/f_pmc_valu [profiles/valu_issue.json c4] > profiles/r01_c4_valu.md
 
 With the two optional arguments the issue fractions are also stored in that JSON file under the given configuration
 name (bench.py quotes the dominant kernel's figure next to its HBM roofline).
 
-Units on gfx950: SQ_INSTS_* count wave-instructions; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles
-summed over waves; GRBM_GUI_ACTIVE is the sum of the 8 XCDs' busy cycles.  A SIMD issues at most one wave64 FP32
-instruction every 2 cycles with several waves resident, so
+Units on gfx950: SQ_INSTS_* count wave-instructions; SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles summed over waves;
+SQ_LDS_IDX_ACTIVE counts the cycles the CUs' LDS arrays are busy, summed over the 256 CUs; GRBM_GUI_ACTIVE is the sum of
+the 8 XCDs' busy cycles.
     valu_issue_fraction = SQ_INSTS_VALU * 2 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
-is the fraction of the plain-FMA issue peak; transcendental, DPP, lane-swap and packed instructions cost more than
-one slot (tools/probes/valu_rate_probe.hip), so a kernel built from them saturates the vector ALU below 1.0.
+is the fraction of a peak of one wave64 FP32 instruction per 2 cycles per SIMD.  That peak is nominal: a loop of
+independent v_fma_f32 at full occupancy sustains one per 2.7 cycles (tools/probes/valu_rate_probe.hip), transcendental,
+DPP, lane-swap and packed instructions cost 1.5 to 3 times that, and no kernel of this library, whatever its mix and
+occupancy, has been seen above one vector instruction per 3.6 cycles per SIMD (fraction 0.55).
+    lds_busy_fraction = SQ_LDS_IDX_ACTIVE / (256 CUs * GRBM_GUI_ACTIVE / 8)
 """
 import collections
 import csv
@@ -35,8 +38,9 @@ def main():
             tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
             launches[k].add(r["Dispatch_Id"])
     print("| kernel | launches | VALU wave-instr / launch | SALU | LDS | cycles (per XCD) | VALU issue fraction | "
-          "waves resident per SIMD | wave time waiting on memory/LDS counters | wave time stalled at issue |")
-    print("|---|---|---|---|---|---|---|---|---|---|")
+          "LDS busy fraction | waves resident per SIMD | wave time waiting on memory/LDS counters | "
+          "wave time stalled at issue |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     fractions = {}
     for k in sorted(tot, key=lambda k: -tot[k].get("GRBM_GUI_ACTIVE", 0)):
         c, n = tot[k], len(launches[k])
@@ -46,9 +50,9 @@ def main():
         valu = c["SQ_INSTS_VALU"] / n
         wave_q = c.get("SQ_WAVE_CYCLES", 0) / n
         fractions[k.split("<")[0].replace("_kernel", "")] = round(valu * 2 / (SIMDS * cyc), 4)
-        print("| `%s` | %d | %.3g | %.3g | %.3g | %.3g | %.2f | %.1f | %.0f %% | %.0f %% |" % (
+        print("| `%s` | %d | %.3g | %.3g | %.3g | %.3g | %.2f | %.2f | %.1f | %.0f %% | %.0f %% |" % (
             k, n, valu, c.get("SQ_INSTS_SALU", 0) / n, c.get("SQ_INSTS_LDS", 0) / n, cyc,
-            valu * 2 / (SIMDS * cyc), wave_q * 4 / (SIMDS * cyc),
+            valu * 2 / (SIMDS * cyc), c.get("SQ_LDS_IDX_ACTIVE", 0) / n / (256 * cyc), wave_q * 4 / (SIMDS * cyc),
             100 * c.get("SQ_WAIT_ANY", 0) / n / wave_q if wave_q else 0,
             100 * c.get("SQ_WAIT_INST_ANY", 0) / n / wave_q if wave_q else 0))
     if len(sys.argv) > 3:
