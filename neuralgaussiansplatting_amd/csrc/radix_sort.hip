@@ -72,10 +72,25 @@ __global__ __launch_bounds__(ST) void sort_hist_kernel(const uint32_t* __restric
     for (int w = 0; w < SWAVES; w++) s_cnt[w][tid] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * STILE;
+    if (base + STILE <= n && (uintptr_t)keys % 16 == 0) {
+        // a full tile: four 16-byte loads per thread, all in flight before the first key is counted (the order in
+        // which a histogram meets its keys does not matter)
+        uint4 k4[SI / 4];
 #pragma unroll
-    for (int i = 0; i < SI; i++) {
-        const int64_t p = base + i * ST + tid;
-        if (p < n) atomicAdd(&s_cnt[wave][digit_of(keys[p], shift, mask)], 1u);
+        for (int i = 0; i < SI / 4; i++) k4[i] = ((const uint4*)(keys + base))[i * ST + tid];
+#pragma unroll
+        for (int i = 0; i < SI / 4; i++) {
+            atomicAdd(&s_cnt[wave][digit_of(k4[i].x, shift, mask)], 1u);
+            atomicAdd(&s_cnt[wave][digit_of(k4[i].y, shift, mask)], 1u);
+            atomicAdd(&s_cnt[wave][digit_of(k4[i].z, shift, mask)], 1u);
+            atomicAdd(&s_cnt[wave][digit_of(k4[i].w, shift, mask)], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SI; i++) {
+            const int64_t p = base + i * ST + tid;
+            if (p < n) atomicAdd(&s_cnt[wave][digit_of(keys[p], shift, mask)], 1u);
+        }
     }
     __syncthreads();
     uint32_t c = 0;
