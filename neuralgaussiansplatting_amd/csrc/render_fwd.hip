@@ -7,7 +7,7 @@
 // issued before the current one is processed), tests whether the splat can
 // reach the wave's block at all (minimum of its quadratic form over the block against the opacity threshold, render_common.h),
 // parks the 48-byte record in the wave's private LDS slice, and the wave then
-// walks only the set bits of the wave-uniform ballot mask, reading each record
+// walks only the set bits of the wave-uniform ballot mask, four at a time, reading each record
 // back as three broadcast LDS loads.  A wave whose 64 pixels are all saturated
 // simply leaves; nobody waits for the slowest block of the tile.
 //
@@ -101,19 +101,27 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
             T = blend ? test_T : T;
             last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
         };
-        // Two surviving splats per trip: both records are requested before the first is used, so the second's LDS
-        // latency passes behind the first's arithmetic, and the loop's scalar bookkeeping is paid once per pair.
+        // Four surviving splats per trip: all records are requested before the first is used, so their LDS latency
+        // passes behind the arithmetic, and the loop's scalar bookkeeping is paid once per four.
         while (mask) {
-            const int j0 = lowest_lane(mask);
-            mask &= mask - 1ull;
-            const bool pair = mask != 0ull;
-            const int j1 = pair ? lowest_lane(mask) : j0;
-            mask &= mask - 1ull;  // 0 stays 0
-            const float4 p0 = rec[j0][0], q0 = rec[j0][1], c0 = rec[j0][2];
-            const float4 p1 = rec[j1][0], q1 = rec[j1][1], c1 = rec[j1][2];
-            asm volatile("" ::"v"(c0.w), "v"(c1.w));  // 16-byte LDS reads (a 12-byte one costs twice the LDS cycles)
-            visit(j0, p0, q0, c0);
-            if (pair) visit(j1, p1, q1, c1);
+            int j[4];
+            bool on[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                on[k] = mask != 0ull;
+                j[k] = on[k] ? lowest_lane(mask) : j[k ? k - 1 : 0];
+                mask &= mask - 1ull;  // 0 stays 0
+            }
+            float4 p[4], q[4], c[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                p[k] = rec[j[k]][0]; q[k] = rec[j[k]][1]; c[k] = rec[j[k]][2];
+                asm volatile("" ::"v"(c[k].w));  // 16-byte LDS reads (a 12-byte one costs twice the LDS cycles)
+            }
+            visit(j[0], p[0], q[0], c[0]);
+            if (on[1]) visit(j[1], p[1], q[1], c[1]);
+            if (on[2]) visit(j[2], p[2], q[2], c[2]);
+            if (on[3]) visit(j[3], p[3], q[3], c[3]);
             // has the whole block saturated?  (a saturated pixel ignores further splats anyway)
             if (wave_mask(!done) == 0ull) break;
         }
