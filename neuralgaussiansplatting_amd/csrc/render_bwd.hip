@@ -141,12 +141,17 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
     __shared__ int s_steps[4];
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    // the list entry a thread stages next: fetched a round ahead, so that a round's staging is one dependent memory
+    // round trip (the records) instead of two
+    uint32_t next_id = 0;
+    if (tid < BWD_BATCH && (int)tmax - 1 - tid >= 0) next_id = plist[range.x + (uint32_t)((int)tmax - 1 - tid)];
     for (int r = 0; r < rounds; r++) {
         __syncthreads();  // previous batch fully flushed before its LDS is reused
         const int first = (int)tmax - 1 - r * BWD_BATCH;  // list position of slot 0
         const int nb = min(BWD_BATCH, first + 1);
         if (tid < nb) {
-            const uint32_t id = plist[range.x + (uint32_t)(first - tid)];
+            const uint32_t id = next_id;
+            if (first - BWD_BATCH - tid >= 0) next_id = plist[range.x + (uint32_t)(first - BWD_BATCH - tid)];
             const float4* gr = splat_rec + 4 * (size_t)id;  // one 64-byte line per splat
             const float4 a = gr[0];
             const float4 b = gr[1];
