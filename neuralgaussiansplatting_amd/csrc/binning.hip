@@ -255,7 +255,19 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
         const uint2 r = s_rect[wave * 64 + j];
         const uint32_t x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu;
         const uint32_t w = x1 - x0;
-        const uint32_t ty = y0 + local / w, tx = x0 + local % w;
+        // row and column of the local-th tile of the rectangle: local / w and local % w.  An integer division by a
+        // variable costs some 25 vector instructions; below 2^22 a float reciprocal is off by at most one.
+        uint32_t qy, qx;
+        if (local < (1u << 22)) {
+            qy = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)w));
+            qx = local - qy * w;
+            if ((int32_t)qx < 0) { qy--; qx += w; }
+            else if (qx >= w) { qy++; qx -= w; }
+        } else {
+            qy = local / w;
+            qx = local % w;
+        }
+        const uint32_t ty = y0 + qy, tx = x0 + qx;
         // the tile id above the high part of the depth rank (the low part rides in the list word)
         const uint2 ir = s_id[wave * 64 + j];
         keys[(size_t)wave_base + k] = ((ty * (uint32_t)grid_x + tx) << dr.key_bits) | ir.y;

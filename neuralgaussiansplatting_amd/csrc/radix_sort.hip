@@ -285,7 +285,7 @@ __device__ __forceinline__ void block_rank_pass(const uint32_t (&key)[ITEMS], in
 #define SEG_ITEMS 16
 #define SEG_BUCKET_LIMIT 128
 template <int THREADS, bool RANKED>
-__global__ __launch_bounds__(THREADS) void segment_sort_bucket_kernel(int T, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 5 : 2) void segment_sort_bucket_kernel(int T, const uint2* __restrict__ ranges,
                                                                       const float* __restrict__ depth,
                                                                       const uint32_t* __restrict__ keys0,
                                                                       const DepthRank dr,
@@ -300,7 +300,9 @@ __global__ __launch_bounds__(THREADS) void segment_sort_bucket_kernel(int T, con
     __shared__ uint32_t s_cnt[NB];   // bucket sizes, then each bucket's cursor (its end once all entries sit)
     __shared__ uint32_t s_key[CAP];  // depth bits grouped by bucket
     __shared__ uint16_t s_slot[CAP]; // and where in the incoming list each came from
-    __shared__ uint32_t s_red[3][WAVES];
+    // the three rows of per-wave partial results live in the first words of s_key, which is not written before the last
+    // of them has been read (a barrier lies between): on their own they would push the kernel past a fifth of the LDS
+    uint32_t(*const s_red)[WAVES] = (uint32_t(*)[WAVES])s_key;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n_work = in < 0 ? (uint32_t)T : hard[in];
     for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {  // one trip when every tile has its own workgroup
