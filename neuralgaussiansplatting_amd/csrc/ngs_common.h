@@ -16,10 +16,15 @@
 #define NGS_ACC_STRIDE 16    // floats per Gaussian in the 64-byte gradient accumulator rows
 #define NGS_ALIGN 256
 
-// Slots of one accumulator row filled by the backward compositing kernel.
-#define NGS_MISC_DMIN 2
-#define NGS_MISC_DMAX 3
+// Words of the geometry buffer's `misc` array beyond [0] (instance count) and [1] (error flags).
+#define NGS_MISC_DMIN 2       // lower bound of the visible Gaussians' depth bits
+#define NGS_MISC_DMAX 3       // upper bound
 #define NGS_MISC_ACC_CLEAN 4  // 1: the gradient accumulator rows are all zero (the forward pass left them so)
+// Slots of one accumulator row filled by the backward compositing kernel, summed over the pixels a Gaussian was
+// blended at (d = Gaussian centre - pixel, G = exp(power), o = opacity): DX, DY = sum of o dL/dalpha G d;
+// CON_A, CON_B, CON_C = sum of o dL/dalpha G (dx^2, dx dy, dy^2); OPAC = sum of dL/dalpha G = dL/dopacity;
+// R, G, B = dL/dcolour.  The per-Gaussian backward kernel turns the first five into dL/dmean2D and dL/dconic with
+// the Gaussian's conic (backward.cu:545-551).
 enum { ACC_DX = 0, ACC_DY, ACC_CON_A, ACC_CON_B, ACC_CON_C, ACC_OPAC, ACC_R, ACC_G, ACC_B, ACC_USED };
 
 // ---------------------------------------------------------------------------

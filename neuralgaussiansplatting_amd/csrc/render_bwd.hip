@@ -13,12 +13,19 @@
 //    and then all four rows step through their lists side by side.  A small
 //    quadrant is touched by far fewer splats than a tile, and a touching splat
 //    covers most of its pixels, so few lanes run the arithmetic for nothing.
+//  * What a pixel hands on per splat: the reference adds nine gradient terms
+//    per (pixel, splat) pair.  Five of them are products of a per-splat
+//    constant (conic, opacity) with a moment of dL/dG over the pixel's offset
+//    from the splat centre; here the pixels sum the moments, and the conic is
+//    applied once per Gaussian by the per-Gaussian backward kernel.
 //  * Reduction: the reference issues nine global float atomics per (pixel,
 //    splat) pair.  Here the nine partials are summed over the 16 pixels of the
 //    quadrant in registers (a reduce-scatter of DPP row exchanges: after four
-//    steps nine lanes of the row hold one total each), then across quadrants
-//    and waves in an LDS table holding one row per staged splat, and each
-//    splat's row leaves the workgroup once per batch as ONE 64-byte-row group
+//    steps nine lanes of the row hold one total each), then across the wave's
+//    steps in a table of sums the wave owns in LDS (plain read, add, write:
+//    no LDS float atomic unless two rows meet on one splat), the workgroup's
+//    four tables are added up when a round of 128 splats is flushed, and each
+//    splat's row leaves the workgroup once per round as ONE 64-byte-row group
 //    of global atomics into the [P][16] accumulator.
 #include "render_common.h"
 
