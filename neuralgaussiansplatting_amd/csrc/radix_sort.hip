@@ -36,11 +36,12 @@ __device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, uint32_t m
 
 // Rank of this lane's item among the wave's items with the same digit that come earlier in input order, plus
 // the number of such items in earlier rounds (kept in cnt[digit]); updates cnt.  All 64 lanes must call it.
+template <int BITS = 8>
 __device__ __forceinline__ uint32_t wave_rank(uint32_t d, bool valid, uint32_t* cnt, uint64_t lanes_below)
 {
     uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < BITS; b++) {
         const bool bit = (d >> b) & 1u;
         const uint64_t m = __ballot(bit);
         peers &= bit ? m : ~m;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(SCAN_T) void sort_scan_kernel(int nblocks, uint32_t
     if (tid == 0) totals[blockIdx.x] = total;
 }
 
+template <int BITS>
 __global__ __launch_bounds__(ST) void sort_scatter_kernel(const uint32_t* __restrict__ count, int64_t capacity,
                                                           const uint32_t* __restrict__ kin,
                                                           const uint32_t* __restrict__ vin,
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(const uint32_t* __rest
 #pragma unroll
     for (int i = 0; i < SI; i++) {
         const int slot = wave * (64 * SI) + i * 64 + lane;
-        rank[i] = wave_rank(digit_of(key[i], shift, mask), slot < n_valid, s_cnt[wave], lanes_below);
+        rank[i] = wave_rank<BITS>(digit_of(key[i], shift, mask), slot < n_valid, s_cnt[wave], lanes_below);
     }
     __syncthreads();
 
@@ -530,7 +532,9 @@ void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t cap
         hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur],
                            first_bit + shift, mask, nblocks, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(SCAN_T), 0, s, nblocks, hist, totals);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur], vals[cur],
+        // the ranking inside a wave costs one ballot per digit bit: the common widths get a kernel of their own
+        auto scatter = width <= 6 ? sort_scatter_kernel<6> : width == 7 ? sort_scatter_kernel<7> : sort_scatter_kernel<8>;
+        hipLaunchKernelGGL(scatter, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur], vals[cur],
                            keys[cur ^ 1], vals[cur ^ 1], first_bit + shift, mask, nblocks, hist, totals);
         cur ^= 1;
     }
