@@ -93,17 +93,20 @@ __device__ __forceinline__ int tile_local_y(int tid)
 }
 
 // exp(x) for the compositing kernels, whose argument is the Gaussian exponent: never positive when it is used.
-// Same operation sequence as the device library's expf (argument reduction by log2(e) in two parts, v_exp_f32,
-// ldexp), so the result is bit-identical for x <= 0, but without expf's two range guards: for x below -103.3
-// expf returns exactly 0 while this returns at most a denormal (alpha then fails the 1/255 test either way),
-// and positive arguments are rejected by the caller before the value is used.
+// One hardware exp2 of the rounded product x * log2(e), then a first-order correction for what the rounding dropped
+// (the product's error, recovered exactly by an fma, plus the low word of log2(e)): exp2(p + d) = exp2(p) (1 + d ln 2)
+// for |d| < 1e-6.  Six instructions against the nine of the device library's expf (which reduces the argument to
+// [-0.5, 0.5], takes exp2 of that and scales by ldexp); over (-16, 0] the result is within 1.26 ulp of the exact value
+// (expf: 0.86) and equals expf in three cases out of four, one ulp off in the fourth (tools/probes/exp_short_probe.hip).
+// Forward and backward pass use this same function, so the backward pass recomputes the forward's alpha bit for bit.
+// Arguments far below the range are harmless: exp2 underflows to zero and alpha fails the 1/255 test.
 __device__ __forceinline__ float exp_nonpos(float x)
 {
     const float log2e_hi = __builtin_bit_cast(float, 0x3fb8aa3bu), log2e_lo = __builtin_bit_cast(float, 0x32a5705fu);
     const float ph = x * log2e_hi;
-    const float pl = fmaf(x, log2e_lo, fmaf(x, log2e_hi, -ph));
-    const float n = rintf(ph);
-    return ldexpf(__builtin_amdgcn_exp2f((ph - n) + pl), (int)n);
+    const float d = fmaf(x, log2e_lo, fmaf(x, log2e_hi, -ph));
+    const float e = __builtin_amdgcn_exp2f(ph);
+    return fmaf(e * d, 0.69314718f, e);
 }
 
 // Wave mask of a lane predicate, straight from the comparison that produced it (the generic __ballot first turns

@@ -242,8 +242,9 @@ def test_more_than_65536_tiles(dgr, oracle, depth_order):
     o = oracle_forward(oracle, c)
     assert o["ranges"].shape[0] == 257 * 257 and o["point_list"].size > 100000
     h = run_hip(dgr, c, dL_dpix=dL)
-    check_forward(o, h)
-    check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=float(c["W"] * c["H"]))
+    # 17 M pixels: like the other large images this one is judged with the allowance for pixels on a threshold
+    edge = check_forward(o, h, exact_pixels=False)
+    check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=float(c["W"] * c["H"]), knife_edge_pixels=edge)
 
 
 def test_culled_and_offscreen_gaussians(dgr, oracle, depth_order):
