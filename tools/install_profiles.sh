@@ -4,6 +4,13 @@
 set -e
 TAG=${1:-r01}
 SRC=gpurun_out/final
+# results of earlier collections pile up next to the newest (every run's files carry its process id): keep the newest
+for d in $SRC/trace $SRC/pmc_fetch $SRC/pmc_write $SRC/pmc_valu; do
+    for sub in $d/*/; do
+        newest=$(ls -t $sub | head -1 | sed 's/_.*//')
+        find $sub -type f ! -name "${newest}_*" -delete
+    done
+done
 for c in c1 c2 c3 c4 c5; do cp $SRC/${c}_bench.json profiles/${TAG}_${c}_bench.json; done
 cp $SRC/c4_gloo2_rehearsal.json profiles/${TAG}_c4_gloo2_rehearsal.json
 cp $SRC/train_demo.json profiles/${TAG}_train_demo.json
