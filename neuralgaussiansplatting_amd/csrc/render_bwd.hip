@@ -223,17 +223,21 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
         // Slot addresses as 24-bit multiply-adds: the 48- and 36-byte strides would otherwise cost a quarter-rate
         // 32/64-bit integer multiply each, twice per step.
         const char* const rec_bytes = (const char*)&s_rec[0][0];
+        const int behind = first - (int)last_contributor;  // slots up to this one lie behind everything the pixel blended
         float* const acc_lane = &s_acc[wave][0][0] + max(my_slot, 0);
         // One step of a row: splat `j` of the batch (record p, q, col) against the row's 16 pixels.
         auto step = [&](const int it, const int j, const float4 p, const float4 q, const float4 col, const bool shared) {
             const bool have = it < my_n;
-            const uint32_t pos = (uint32_t)(first - j);  // the reference's `contributor` after its decrement
             const float dx = p.x - pxf, dy = p.y - pyf;
             // same evaluation order as the forward pass (and the reference): alpha must come out bit-identical
             const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
             const float G = exp_nonpos(power);
             const float alpha = fminf(0.99f, q.w * G);
-            const bool live = have && pos < last_contributor && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            // first - j is the reference's `contributor` after its decrement; the pixel blended the splat if that
+            // lies below its last contributor, i.e. if j lies above `behind`.  The alpha test comes last and on its
+            // own, so that the wave's mask of live lanes is that comparison's result as it stands.
+            const float alpha_t = (have && j > behind && !(power > 0.0f)) ? alpha : 0.0f;
+            const bool live = !(alpha_t < 1.0f / 255.0f);
             STAT(0, 1);
             STAT(1, __popcll(wave_mask(have)) / 16);
             STAT(2, __popcll(wave_mask(live)));
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
             float* const entry = acc_lane + __umul24((unsigned)j, (unsigned)ACC_USED);
             const float before = *entry;
             asm volatile("" :: "v"(col.w));  // the colour comes as one 16-byte LDS read (a 12-byte one costs twice the LDS cycles)
-            const float alpha_l = live ? alpha : 0.0f;
+            const float alpha_l = live ? alpha_t : 0.0f;
             const float om = 1.f - alpha_l;
             const float inv = __builtin_amdgcn_rcpf(om);  // v_rcp_f32, 1 ulp; exactly 1 for a dead lane
             const float Tn = T * inv;

@@ -88,8 +88,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
             const float alpha = fminf(0.99f, q.w * exp_nonpos(power));
             const float test_T = T * (1 - alpha);
             const bool hit = !done && power <= 0.0f && !(alpha < 1.0f / 255.0f);
-            const bool stop = hit && test_T < 0.0001f;
-            const bool blend = hit && !stop;
+            const bool blend = hit && !(test_T < 0.0001f);
+            const bool stop = hit && !blend;  // from the masks: one comparison instead of two
             done = done || stop;
             // (colour * alpha) * T added with one rounding, as the reference's build contracts the same expression
             // (forward.cu:355-356 compiled with nvcc's default -fmad=true).  A pixel that does not blend the splat
