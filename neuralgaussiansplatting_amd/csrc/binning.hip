@@ -194,7 +194,12 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void depth_order_kernel(int P, con
     const uint32_t ws = wave_sum_u32(t);
     if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = ws;
     __syncthreads();
-    if (threadIdx.x == 0) s_block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < NGS_GAUSS_BLOCK / 64; w++) sum += wave_tot[w];
+        s_block_sums[blockIdx.x] = sum;
+    }
 }
 
 // `order` == NULL: lane k emits Gaussian k; else Gaussian order[k] (rect / tiles / block_offs are then the arrays

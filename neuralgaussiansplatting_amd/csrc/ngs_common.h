@@ -11,7 +11,9 @@
 #define NGS_TILE_W 16
 #define NGS_TILE_H 16
 #define NGS_TILE_PIX 256
+#ifndef NGS_GAUSS_BLOCK
 #define NGS_GAUSS_BLOCK 256  // Gaussians per workgroup in the per-Gaussian kernels; also the scan granule
+#endif
 #define NGS_MAX_GAUSSIANS (1 << 27)  // entry points refuse more: per-Gaussian offsets are formed in 32-bit lanes
 #define NGS_ACC_STRIDE 16    // floats per Gaussian in the 64-byte gradient accumulator rows
 #define NGS_ALIGN 256

@@ -282,11 +282,16 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        uint32_t sum = 0, blo = 0xffffffffu, bhi = 0u;
+#pragma unroll
+        for (int w = 0; w < NGS_GAUSS_BLOCK / 64; w++) {
+            sum += wave_tot[w];
+            blo = min(blo, wave_dmin[w]);
+            bhi = max(bhi, wave_dmax[w]);
+        }
+        block_sums[blockIdx.x] = sum;
         // bounds, 16 bits each: the smallest depth's high half, and the largest's plus one (a visible depth is a
         // positive finite float, so that still fits); 0xffff and 0 for a block without a visible Gaussian
-        const uint32_t blo = min(min(wave_dmin[0], wave_dmin[1]), min(wave_dmin[2], wave_dmin[3]));
-        const uint32_t bhi = max(max(wave_dmax[0], wave_dmax[1]), max(wave_dmax[2], wave_dmax[3]));
         block_depths[blockIdx.x] = (blo >> 16) | (bhi ? min((bhi >> 16) + 1u, 0xffffu) << 16 : 0u);
     }
 }

@@ -28,6 +28,10 @@ cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
 echo "trace done"
+# the same with nothing but the forward+backward loop in the process: the per-kernel averages bench.py's roofline figures
+# are to be held against (in the full run the training iterations' launches of the same kernels are averaged in)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_hot -- python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-idxmap --train-steps 0 > $OUT/trace_hot.log 2>&1
+echo "hot-path trace done"
 PMC_CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --train-steps 0 --no-idxmap --no-cpu-baseline"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMC_CMD > $OUT/pmc_fetch.log 2>&1
 echo "fetch done"

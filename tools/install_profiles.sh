@@ -5,7 +5,7 @@ set -e
 TAG=${1:-r01}
 SRC=gpurun_out/final
 # results of earlier collections pile up next to the newest (every run's files carry its process id): keep the newest
-for d in $SRC/trace $SRC/pmc_fetch $SRC/pmc_write $SRC/pmc_valu; do
+for d in $SRC/trace $SRC/trace_hot $SRC/pmc_fetch $SRC/pmc_write $SRC/pmc_valu; do
     for sub in $d/*/; do
         newest=$(ls -t $sub | head -1 | sed 's/_.*//')
         find $sub -type f ! -name "${newest}_*" -delete
@@ -19,6 +19,10 @@ for f in c4_gloo2_views2_rehearsal c4_bench_unfused_train c4_bench_views2 c4_foo
 done
 cp $SRC/trace/*/*_kernel_stats.csv profiles/${TAG}_c4_final_kernel_stats.csv
 python3 tools/kernel_stats_md.py profiles/${TAG}_c4_final_kernel_stats.csv "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline" > profiles/${TAG}_c4_final_kernel_stats.md
+if [ -d $SRC/trace_hot ]; then
+    cp $SRC/trace_hot/*/*_kernel_stats.csv profiles/${TAG}_c4_hot_path_kernel_stats.csv
+    python3 tools/kernel_stats_md.py profiles/${TAG}_c4_hot_path_kernel_stats.csv "python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-idxmap --train-steps 0" > profiles/${TAG}_c4_hot_path_kernel_stats.md
+fi
 python3 tools/pmc_summary.py --fetch $SRC/pmc_fetch --write $SRC/pmc_write --config c4 \
     --out profiles/hbm_traffic.json --raw profiles/${TAG}_c4_pmc_traffic.json
 python3 tools/pmc_valu_summary.py $SRC/pmc_valu profiles/valu_issue.json c4 profiles/${TAG}_c4_valu.md > profiles/${TAG}_c4_valu.md
