@@ -70,7 +70,7 @@ extern "C" int ngs_debug_bwd_stats(unsigned long long* out)
 #define STAT(k, v)
 #endif
 
-__global__ __launch_bounds__(NGS_TILE_PIX) void render_bwd_kernel(
+__global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
     const float4* __restrict__ splat_rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ acc, uint32_t* __restrict__ misc)
