@@ -166,17 +166,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
     }
 }
 
-// One workgroup per 256 Gaussians (the same blocks as the preprocess kernel).
-// Each wave owns 64 consecutive Gaussians, whose instances occupy one
-// contiguous run of the output; the wave walks that run 64 entries at a time,
-// each lane locating its Gaussian by binary search over the wave's prefix sums,
-// so key/value stores are fully coalesced whatever the footprint sizes are.
-// Instances beyond `capacity` (a binning buffer sized from an estimate that turned out too small) are dropped and
-// flagged in misc[1]; the host then runs the stages again with a buffer that fits.
-// Gather of the per-Gaussian tile counts and rectangles into depth order, and the per-block sums of the counts in
-// that order (first level of the offset scan).  One lane per position of the order.
+// Gather of the per-Gaussian rectangles into depth order, the tile counts in that order (a rectangle's area) and their
+// per-block sums (first level of the offset scan).  One lane per position of the order.  Whether a position holds
+// a Gaussian that emits instances is read off its sorted key (culled Gaussians sort to the end under a key of all
+// ones), so the one dependent access per position is the rectangle's.
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void depth_order_kernel(int P, const uint32_t* __restrict__ order,
-                                                                      const uint32_t* __restrict__ tiles,
+                                                                      const uint32_t* __restrict__ sorted_keys,
                                                                       const uint2* __restrict__ rect,
                                                                       uint32_t* __restrict__ s_tiles,
                                                                       uint2* __restrict__ s_rect,
@@ -186,10 +181,12 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void depth_order_kernel(int P, con
     const int k = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
     uint32_t t = 0;
     if (k < P) {
-        const uint32_t g = order[k];
-        t = tiles[g];
+        if (sorted_keys[k] != 0xffffffffu) {
+            const uint2 r = rect[order[k]];
+            t = ((r.x >> 16) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.y & 0xffffu));
+            s_rect[k] = r;
+        }
         s_tiles[k] = t;
-        if (t) s_rect[k] = rect[g];
     }
     const uint32_t ws = wave_sum_u32(t);
     if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = ws;
@@ -202,6 +199,13 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void depth_order_kernel(int P, con
     }
 }
 
+// One workgroup per 256 Gaussians (the same blocks as the preprocess kernel).
+// Each wave owns 64 consecutive Gaussians, whose instances occupy one
+// contiguous run of the output; the wave walks that run 64 entries at a time,
+// each lane locating its Gaussian by binary search over the wave's prefix sums,
+// so key/value stores are fully coalesced whatever the footprint sizes are.
+// Instances beyond `capacity` (a binning buffer sized from an estimate that turned out too small) are dropped and
+// flagged in misc[1]; the host then runs the stages again with a buffer that fits.
 // `order` == NULL: lane k emits Gaussian k; else Gaussian order[k] (rect / tiles / block_offs are then the arrays
 // in that order).
 __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const uint2* __restrict__ rect,
@@ -344,11 +348,11 @@ void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* bloc
                        block_sums, block_offs, block_depths, misc, mailbox);
 }
 
-void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, const uint2* rect,
+void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const uint32_t* sorted_keys, const uint2* rect,
                             uint32_t* s_tiles, uint2* s_rect, uint32_t* s_block_sums, uint32_t* s_block_offs)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
-    hipLaunchKernelGGL(depth_order_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, order, tiles, rect, s_tiles,
+    hipLaunchKernelGGL(depth_order_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, order, sorted_keys, rect, s_tiles,
                        s_rect, s_block_sums);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, s_block_sums, s_block_offs,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr);

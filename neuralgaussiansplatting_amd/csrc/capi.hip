@@ -378,7 +378,7 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         prof_begin(ps, ST_DEPTHSORT, st);
         ngs_launch_sort_tile_bits(st, nullptr, P, dkeys, order, (uint32_t*)(gb + gl.dhist), (uint32_t*)(gb + gl.dtotals),
                                   32);
-        ngs_launch_depth_order(st, P, order[0], tiles, rect, s_tiles, s_rect, s_block_sums, s_block_offs);
+        ngs_launch_depth_order(st, P, order[0], dkeys[0], rect, s_tiles, s_rect, s_block_sums, s_block_offs);
         prof_end(ps, ST_DEPTHSORT, st);
         NGS_STAGE("depth order");
     }

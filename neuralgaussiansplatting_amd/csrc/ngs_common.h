@@ -293,10 +293,11 @@ void ngs_launch_scan_block_sums(hipStream_t s, int nblocks, const uint32_t* bloc
 // The stages between the scan and the compositing take the instance count from DEVICE memory (`count`, the word
 // the scan kernel wrote) and a capacity: launches are sized by the capacity, kernels work on min(count, capacity)
 // instances, so they can be queued before the host knows the count and never step outside the buffer.
-// ngs_launch_depth_order: from the Gaussian indices sorted by depth, the tile counts and rectangles in that order
-// and the exclusive prefix of the counts per block of 256.  ngs_launch_duplicate then emits the instances of the
-// k-th Gaussian IN DEPTH ORDER at its offset; the value of each instance is order[k].
-void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, const uint2* rect,
+// ngs_launch_depth_order: from the Gaussian indices sorted by depth and their sorted keys (all ones = emits no
+// instance), the rectangles and tile counts in that order and the exclusive prefix of the counts per block of 256.
+// ngs_launch_duplicate then emits the instances of the k-th Gaussian IN DEPTH ORDER at its offset; the value of each
+// instance is order[k].
+void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const uint32_t* sorted_keys, const uint2* rect,
                             uint32_t* s_tiles, uint2* s_rect, uint32_t* s_block_sums, uint32_t* s_block_offs);
 // Keys are (tile id << dr.key_bits) | high part of the depth rank, list words Gaussian index | low part of the rank
 // << dr.idx_bits (see DepthRank); dr.key_bits == 0: the tile id and the index alone.
