@@ -59,7 +59,7 @@ struct GeomLayout {
     size_t s_rect;     // uint2 [P]  packed tile rectangle, in depth order
     size_t s_block_sums; // u32 [ceil(P/256)] tiles touched per 256 Gaussians in depth order
     size_t s_block_offs; // u32 [ceil(P/256)] exclusive prefix of s_block_sums
-    size_t dhist;      // u32   [256 * sort_blocks(P)] histogram of the depth passes
+    size_t dhist;      // u32   [256 * ngs_sort_blocks(P)] histogram of the depth passes
     size_t dtotals;    // u32   [256]
     size_t block_depths; // u32 [ceil(P/256)] depth bounds of the block's visible Gaussians, high halves of the depth
                        //            bits: low 16 = smallest, rounded down; high 16 = largest, rounded up (0xffff and 0
@@ -82,7 +82,7 @@ struct BinLayout {
     size_t vals[2];  // u32[C] ping/pong; vals[0] (offset 0) is the sorted point list
     size_t keys[2];  // u32[C] each: tile ids, ping/pong of the tile-level sort (then depth-bit scratch of the general
                      // per-tile sort)
-    size_t hist;     // u32[256 * sort_blocks(C)] digit-major per-block histogram
+    size_t hist;     // u32[256 * ngs_sort_blocks(C)] digit-major per-block histogram
     size_t totals;   // u32[256] per-digit totals
     size_t total;
 };
@@ -92,6 +92,16 @@ static inline size_t ngs_align_up(size_t v) { return (v + NGS_ALIGN - 1) & ~(siz
 #define NGS_SORT_THREADS 256
 #define NGS_SORT_ITEMS 16
 #define NGS_SORT_TILE (NGS_SORT_THREADS * NGS_SORT_ITEMS)
+// Pairs per workgroup of a radix pass over `count` pairs: 4096 (the more pairs a workgroup holds, the longer the runs
+// it writes per digit: at 3 M pairs and 8-bit digits 1024 cost 40 us more over four passes), but 1024 below a million
+// pairs (the instances of a small scene), where 4096 would give fewer workgroups than there are CUs.
+#define NGS_SORT_SMALL ((size_t)1 << 20)
+static inline int ngs_sort_items(size_t count) { return count < NGS_SORT_SMALL ? 4 : NGS_SORT_ITEMS; }
+static inline size_t ngs_sort_blocks(size_t count)
+{
+    const size_t tile = (size_t)NGS_SORT_THREADS * ngs_sort_items(count);
+    return (count + tile - 1) / tile;
+}
 
 static inline GeomLayout ngs_geom_layout(size_t P)
 {
@@ -113,7 +123,7 @@ static inline GeomLayout ngs_geom_layout(size_t P)
     l.s_rect = o; o = ngs_align_up(o + P * 8);
     l.s_block_sums = o; o = ngs_align_up(o + nb * 4);
     l.s_block_offs = o; o = ngs_align_up(o + nb * 4);
-    l.dhist = o; o = ngs_align_up(o + ((P + NGS_SORT_TILE - 1) / NGS_SORT_TILE) * 256 * 4);
+    l.dhist = o; o = ngs_align_up(o + ngs_sort_blocks(P) * 256 * 4);
     l.dtotals = o; o = ngs_align_up(o + 256 * 4);
     l.block_depths = o; o = ngs_align_up(o + nb * 4);
     l.total = o + NGS_ALIGN;
@@ -186,7 +196,7 @@ static inline ImageLayout ngs_image_layout(int W, int H)
 static inline BinLayout ngs_bin_layout(size_t C)
 {
     BinLayout l;
-    size_t o = 0, nb = (C + NGS_SORT_TILE - 1) / NGS_SORT_TILE;
+    size_t o = 0, nb = ngs_sort_blocks(C);
     l.vals[0] = o; o = ngs_align_up(o + C * 4);
     l.vals[1] = o; o = ngs_align_up(o + C * 4);
     l.keys[0] = o; o = ngs_align_up(o + C * 4);

@@ -59,28 +59,30 @@ __device__ __forceinline__ int64_t pair_count(const uint32_t* count, int64_t cap
     return count ? min((int64_t)*count, capacity) : capacity;
 }
 
+template <int ITEMS>
 __global__ __launch_bounds__(ST) void sort_hist_kernel(const uint32_t* __restrict__ count, int64_t capacity,
                                                        const uint32_t* __restrict__ keys, int shift,
                                                        uint32_t mask, int nblocks, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t s_cnt[SWAVES][256];
+    constexpr int TILE = ST * ITEMS;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int64_t n = pair_count(count, capacity);
-    if ((int64_t)blockIdx.x * STILE >= n) {  // a block past the end (launches are sized by the capacity)
+    if ((int64_t)blockIdx.x * TILE >= n) {  // a block past the end (launches are sized by the capacity)
         hist[(size_t)tid * nblocks + blockIdx.x] = 0;
         return;
     }
     for (int w = 0; w < SWAVES; w++) s_cnt[w][tid] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * STILE;
-    if (base + STILE <= n && (uintptr_t)keys % 16 == 0) {
+    const int64_t base = (int64_t)blockIdx.x * TILE;
+    if (base + TILE <= n && (uintptr_t)keys % 16 == 0) {
         // a full tile: four 16-byte loads per thread, all in flight before the first key is counted (the order in
         // which a histogram meets its keys does not matter)
-        uint4 k4[SI / 4];
+        uint4 k4[ITEMS / 4];
 #pragma unroll
-        for (int i = 0; i < SI / 4; i++) k4[i] = ((const uint4*)(keys + base))[i * ST + tid];
+        for (int i = 0; i < ITEMS / 4; i++) k4[i] = ((const uint4*)(keys + base))[i * ST + tid];
 #pragma unroll
-        for (int i = 0; i < SI / 4; i++) {
+        for (int i = 0; i < ITEMS / 4; i++) {
             atomicAdd(&s_cnt[wave][digit_of(k4[i].x, shift, mask)], 1u);
             atomicAdd(&s_cnt[wave][digit_of(k4[i].y, shift, mask)], 1u);
             atomicAdd(&s_cnt[wave][digit_of(k4[i].z, shift, mask)], 1u);
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(ST) void sort_hist_kernel(const uint32_t* __restric
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < SI; i++) {
+        for (int i = 0; i < ITEMS; i++) {
             const int64_t p = base + i * ST + tid;
             if (p < n) atomicAdd(&s_cnt[wave][digit_of(keys[p], shift, mask)], 1u);
         }
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(SCAN_T) void sort_scan_kernel(int nblocks, uint32_t
     if (tid == 0) totals[blockIdx.x] = total;
 }
 
-template <int BITS>
+template <int BITS, int ITEMS>
 __global__ __launch_bounds__(ST) void sort_scatter_kernel(const uint32_t* __restrict__ count, int64_t capacity,
                                                           const uint32_t* __restrict__ kin,
                                                           const uint32_t* __restrict__ vin,
@@ -144,30 +146,31 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(const uint32_t* __rest
     __shared__ uint32_t s_gofs[256];         // global position of local slot 0 of each digit (minus s_start)
     __shared__ uint32_t s_wtot[SWAVES];
     __shared__ uint32_t s_gwtot[SWAVES];
-    __shared__ uint32_t s_key[STILE];
-    __shared__ uint32_t s_val[STILE];
+    constexpr int TILE = ST * ITEMS;
+    __shared__ uint32_t s_key[TILE];
+    __shared__ uint32_t s_val[TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n = pair_count(count, capacity);
-    const int64_t base = (int64_t)blockIdx.x * STILE;
+    const int64_t base = (int64_t)blockIdx.x * TILE;
     if (base >= n) return;  // block-uniform
-    const int n_valid = (int)min((int64_t)STILE, n - base);
+    const int n_valid = (int)min((int64_t)TILE, n - base);
     for (int w = 0; w < SWAVES; w++) s_cnt[w][tid] = 0;
     __syncthreads();
 
-    // Wave-striped ownership keeps input order: wave w owns slots [w*64*SI, (w+1)*64*SI), item i of lane l is
-    // slot w*64*SI + i*64 + l.
-    uint32_t key[SI], val[SI], rank[SI];
+    // Wave-striped ownership keeps input order: wave w owns slots [w*64*ITEMS, (w+1)*64*ITEMS), item i of lane l is
+    // slot w*64*ITEMS + i*64 + l.
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
     const uint64_t lanes_below = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int i = 0; i < SI; i++) {
-        const int slot = wave * (64 * SI) + i * 64 + lane;
+    for (int i = 0; i < ITEMS; i++) {
+        const int slot = wave * (64 * ITEMS) + i * 64 + lane;
         const bool valid = slot < n_valid;
         key[i] = valid ? kin[base + slot] : ~0u;
         val[i] = valid ? vin[base + slot] : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < SI; i++) {
-        const int slot = wave * (64 * SI) + i * 64 + lane;
+    for (int i = 0; i < ITEMS; i++) {
+        const int slot = wave * (64 * ITEMS) + i * 64 + lane;
         rank[i] = wave_rank<BITS>(digit_of(key[i], shift, mask), slot < n_valid, s_cnt[wave], lanes_below);
     }
     __syncthreads();
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(const uint32_t* __rest
     __syncthreads();
 
 #pragma unroll
-    for (int i = 0; i < SI; i++) {
-        const int slot = wave * (64 * SI) + i * 64 + lane;
+    for (int i = 0; i < ITEMS; i++) {
+        const int slot = wave * (64 * ITEMS) + i * 64 + lane;
         if (slot < n_valid) {
             const uint32_t d = digit_of(key[i], shift, mask);
             const uint32_t pos = s_start[d] + s_cnt[wave][d] + rank[i];
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(ST) void sort_scatter_kernel(const uint32_t* __rest
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < SI; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const int pos = i * ST + tid;
         if (pos < n_valid) {
             const uint32_t k = s_key[pos];
@@ -517,11 +520,11 @@ static int tile_passes(int bits) { return (bits + 7) / 8; }
 
 int ngs_sort_input_buffer(int bits) { return tile_passes(bits) & 1; }
 
-void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
+template <int ITEMS>
+static void launch_sort_passes(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
                                uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits, int first_bit)
 {
-    if (capacity <= 0) return;
-    const int nblocks = (int)((capacity + STILE - 1) / STILE);
+    const int nblocks = (int)((capacity + ST * ITEMS - 1) / (ST * ITEMS));
     int cur = ngs_sort_input_buffer(bits);
     // the bits are spread evenly over the passes (13 bits: 7 + 6, not 8 + 5): fewer buckets in a pass mean longer
     // runs per bucket in the scatter, i.e. fewer partially written memory lines
@@ -529,15 +532,28 @@ void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t cap
     for (int shift = 0, width; shift < bits; shift += width, passes_left--) {
         width = (bits - shift + passes_left - 1) / passes_left;
         const uint32_t mask = (1u << width) - 1u;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur],
+        hipLaunchKernelGGL(sort_hist_kernel<ITEMS>, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur],
                            first_bit + shift, mask, nblocks, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(SCAN_T), 0, s, nblocks, hist, totals);
         // the ranking inside a wave costs one ballot per digit bit: the common widths get a kernel of their own
-        auto scatter = width <= 6 ? sort_scatter_kernel<6> : width == 7 ? sort_scatter_kernel<7> : sort_scatter_kernel<8>;
+        auto scatter = width <= 6   ? sort_scatter_kernel<6, ITEMS>
+                       : width == 7 ? sort_scatter_kernel<7, ITEMS>
+                                    : sort_scatter_kernel<8, ITEMS>;
         hipLaunchKernelGGL(scatter, dim3(nblocks), dim3(ST), 0, s, count, capacity, keys[cur], vals[cur],
                            keys[cur ^ 1], vals[cur ^ 1], first_bit + shift, mask, nblocks, hist, totals);
         cur ^= 1;
     }
+}
+
+// hist: u32[256 * ngs_sort_blocks(capacity)]
+void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t capacity, uint32_t* const keys[2],
+                               uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits, int first_bit)
+{
+    if (capacity <= 0) return;
+    if (ngs_sort_items((size_t)capacity) == 4)
+        launch_sort_passes<4>(s, count, capacity, keys, vals, hist, totals, bits, first_bit);
+    else
+        launch_sort_passes<NGS_SORT_ITEMS>(s, count, capacity, keys, vals, hist, totals, bits, first_bit);
 }
 
 // The depth order obtained AFTER the tile-level sort instead of before it: one workgroup per tile fetches the depth
