@@ -355,7 +355,7 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     // Where the depth order comes from (both give the same lists): a sort of the P Gaussians before their instances
     // are emitted -- 14 small launches whose cost follows P -- or a sort of every tile's list afterwards -- two
     // launches whose cost follows the instance count and rises steeply once lists outgrow a workgroup (4096
-    // entries).  Measured on MI355X the first costs about 90 us + 48 us per million Gaussians, the second about
+    // entries).  Measured on MI355X the first costs about 50 us + 45 us per million Gaussians, the second about
     // 12 us + 6 us per million instances while no list passes 4096 entries and the instances carry their depth rank
     // (0.085 ms at 1500 per tile on average and 12 M instances), rising steeply where the longest lists do (2900 per
     // tile on average and 24 M instances).
@@ -363,7 +363,7 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     {
         const double inst = (double)capacity, per_tile = inst / (double)T;
         const double by_tile = 12.0 + 6.1e-6 * inst * (per_tile > 2600.0 ? 1.0 + (per_tile - 2600.0) / 150.0 : 1.0);
-        const double by_gaussian = 90.0 + 48e-6 * (double)P;
+        const double by_gaussian = 50.0 + 45e-6 * (double)P;
         depth_first = by_gaussian < by_tile;
         if (g_depth_order_choice >= 0) depth_first = g_depth_order_choice == 1;
     }
