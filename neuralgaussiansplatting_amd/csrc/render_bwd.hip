@@ -251,7 +251,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
             // colour behind it becomes 0 * colour + 1 * rec = rec, and every partial below is an exact zero
             // (G and dL/dalpha are forced to 0 as well).
             // the table entry this lane will add to, on its way while the sums are formed
-            float* const entry = acc_lane + __umul24((unsigned)j, (unsigned)ACC_USED);
+            // (its LDS address is formed once and kept: left to itself the compiler forms it again for the write)
+            typedef __attribute__((address_space(3))) float lds_float;
+            lds_float* entry = (lds_float*)(acc_lane + __umul24((unsigned)j, (unsigned)ACC_USED));
+            asm volatile("" : "+v"(entry));
             const float before = *entry;
             asm volatile("" :: "v"(col.w));  // the colour comes as one 16-byte LDS read (a 12-byte one costs twice the LDS cycles)
             const float alpha_l = live ? alpha_t : 0.0f;
@@ -295,9 +298,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
             const float c07 = row_fold<DPP_QUAD_XOR2>(b03, b47, up2);
             const float c8 = row_pair_sum<DPP_QUAD_XOR2>(b8);
             const float total = row_fold<DPP_QUAD_XOR1>(c07, c8, up1);
+            asm volatile("" ::"v"(total));  // formed here, as one DPP add: not taken apart and half of it moved into the branch below
             if (have && my_slot >= 0) {
                 if (shared) {  // wave-uniform: rows that work on the same splat in this step meet in one entry
-                    if (total != 0.0f) atomicAdd(entry, total);
+                    if (total != 0.0f) atomicAdd((float*)entry, total);
                 } else {
                     *entry = before + total;
                 }
