@@ -216,8 +216,13 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
                                                                     const DepthRank dr, int grid_x,
                                                                     uint32_t* __restrict__ keys,
                                                                     uint32_t* __restrict__ vals, uint32_t capacity,
-                                                                    uint32_t* __restrict__ misc)
+                                                                    uint32_t* __restrict__ misc,
+                                                                    uint4* __restrict__ clear, int clear_n)
 {
+    // The tile ranges (and the counters behind them) have to be zero before the range kernel runs, two launches on:
+    // the first workgroups of this one see to it, which saves a fill launch.
+    for (int k = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x; k < clear_n; k += gridDim.x * NGS_GAUSS_BLOCK)
+        clear[k] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ uint32_t s_incl[NGS_GAUSS_BLOCK];  // per wave: inclusive prefix of tiles within the wave
     __shared__ uint2 s_rect[NGS_GAUSS_BLOCK];
     __shared__ uint2 s_id[NGS_GAUSS_BLOCK];  // x: list word (Gaussian index | low part of the depth rank), y: the
@@ -360,17 +365,17 @@ void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const u
 
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
                           const uint32_t* order, const float* depth, const DepthRank& dr, int grid_x, uint32_t* keys,
-                          uint32_t* vals, int64_t capacity, uint32_t* misc)
+                          uint32_t* vals, int64_t capacity, uint32_t* misc, void* clear, size_t clear_bytes)
 {
     const int nb = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
     hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(NGS_GAUSS_BLOCK), 0, s, P, rect, tiles, block_offs, order,
-                       depth, dr, grid_x, keys, vals, (uint32_t)capacity, misc);
+                       depth, dr, grid_x, keys, vals, (uint32_t)capacity, misc, (uint4*)clear, (int)(clear_bytes / 16));
 }
 
 void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* keys, int qbits,
                             int T, uint2* ranges, size_t clear_bytes)
 {
-    (void)hipMemsetAsync(ranges, 0, clear_bytes > (size_t)T * sizeof(uint2) ? clear_bytes : (size_t)T * sizeof(uint2), s);
+    if (clear_bytes) (void)hipMemsetAsync(ranges, 0, clear_bytes, s);
     if (capacity > 0 && (uintptr_t)keys % 16 == 0)
         hipLaunchKernelGGL(tile_ranges_vec_kernel, dim3((unsigned)((capacity + 1023) / 1024)), dim3(256), 0, s, count,
                            capacity, keys, qbits, ranges);

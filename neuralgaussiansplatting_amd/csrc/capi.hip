@@ -352,6 +352,7 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     const int tile_bits = (int)higher_msb((uint32_t)T);
     const int in_buf = ngs_sort_input_buffer(tile_bits);
     uint2* ranges = (uint2*)(ib + il.ranges);
+    const size_t ranges_clear = il.hard + 16 - il.ranges;  // the ranges and, behind them, the work lists' counters
     // Where the depth order comes from (both give the same lists): a sort of the P Gaussians before their instances
     // are emitted -- 14 small launches whose cost follows P -- or a sort of every tile's list afterwards -- two
     // launches whose cost follows the instance count and rises steeply once lists outgrow a workgroup (4096
@@ -395,10 +396,10 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
             prof_begin(ps, ST_DUPLICATE, st);
             if (depth_first)
                 ngs_launch_duplicate(st, P, s_rect, s_tiles, s_block_offs, order[0], nullptr, dr, cam.grid_x,
-                                     tkeys[in_buf], vals[in_buf], capacity, misc);
+                                     tkeys[in_buf], vals[in_buf], capacity, misc, ranges, ranges_clear);
             else
                 ngs_launch_duplicate(st, P, rect, tiles, block_offs, nullptr, depth, dr, cam.grid_x, tkeys[in_buf],
-                                     vals[in_buf], capacity, misc);
+                                     vals[in_buf], capacity, misc, ranges, ranges_clear);
             prof_end(ps, ST_DUPLICATE, st);
             NGS_STAGE("duplicateWithKeys");
             prof_begin(ps, ST_SORT, st);
@@ -407,8 +408,8 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
             NGS_STAGE("sort");
         }
         prof_begin(ps, ST_RANGES, st);
-        // the same fill also clears the counter of the per-tile sort's work list, which follows the ranges
-        ngs_launch_tile_ranges(st, misc, capacity, tkeys[0], qbits, T, ranges, il.hard + 16 - il.ranges);
+        // (cleared by the emission kernel when that ran: the ranges and the counters of the per-tile sort's work lists)
+        ngs_launch_tile_ranges(st, misc, capacity, tkeys[0], qbits, T, ranges, capacity > 0 ? 0 : ranges_clear);
         prof_end(ps, ST_RANGES, st);
         NGS_STAGE("identifyTileRanges");
         if (capacity > 0 && !depth_first) {

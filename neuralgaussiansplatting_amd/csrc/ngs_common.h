@@ -311,11 +311,14 @@ void ngs_launch_depth_order(hipStream_t s, int P, const uint32_t* order, const u
                             uint32_t* s_tiles, uint2* s_rect, uint32_t* s_block_sums, uint32_t* s_block_offs);
 // Keys are (tile id << dr.key_bits) | high part of the depth rank, list words Gaussian index | low part of the rank
 // << dr.idx_bits (see DepthRank); dr.key_bits == 0: the tile id and the index alone.
+// `clear`: clear_bytes bytes (16-byte aligned, a multiple of 16) the kernel zeroes on the side -- the tile ranges and the
+// counters behind them, which the range kernel two launches on expects zero.
 void ngs_launch_duplicate(hipStream_t s, int P, const uint2* rect, const uint32_t* tiles, const uint32_t* block_offs,
                           const uint32_t* order, const float* depth, const DepthRank& dr, int grid_x,
-                          uint32_t* tile_keys, uint32_t* vals, int64_t capacity, uint32_t* misc);
-// clear_bytes: bytes to zero starting at `ranges` (at least 8 T; the caller extends it over the counter that follows)
-// the tile id of a key is key >> qbits
+                          uint32_t* tile_keys, uint32_t* vals, int64_t capacity, uint32_t* misc, void* clear,
+                          size_t clear_bytes);
+// clear_bytes: bytes to zero starting at `ranges` before the kernel runs (8 T and the counter that follows), 0 when
+// ngs_launch_duplicate has seen to it; the tile id of a key is key >> qbits
 void ngs_launch_tile_ranges(hipStream_t s, const uint32_t* count, int64_t capacity, const uint32_t* tile_keys, int qbits,
                             int T, uint2* ranges, size_t clear_bytes);
 // radix_sort.hip: stable LSD radix sort of (32-bit key, 32-bit value) pairs on bits [first_bit, first_bit + bits) of
