@@ -227,29 +227,40 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
     __shared__ uint2 s_rect[NGS_GAUSS_BLOCK];
     __shared__ uint2 s_id[NGS_GAUSS_BLOCK];  // x: list word (Gaussian index | low part of the depth rank), y: the
                                              // high part of the rank, which goes into every key of the Gaussian
+    __shared__ uint32_t s_excl[NGS_GAUSS_BLOCK];  // and the exclusive one
     __shared__ uint32_t s_wave_tot[NGS_GAUSS_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + tid;
-    uint32_t cnt = 0;
+    // Everything a Gaussian brings is requested at once (a workgroup emits about a thousand instances: a chain of
+    // loads that wait for one another at its start would be most of its life); what a culled Gaussian's rectangle and
+    // depth hold is never used.
+    uint32_t cnt = 0, id = (uint32_t)idx, zbits = 0;
+    uint2 rc = make_uint2(0u, 0u);
+    const bool ranked = depth && dr.key_bits;
+    const uint32_t block_base = block_offs[blockIdx.x];
+    const uint32_t dmin = ranked ? misc[NGS_MISC_DMIN] : 0u, dmax = ranked ? misc[NGS_MISC_DMAX] : 0u;
     if (idx < P) {
         cnt = tiles[idx];
-        if (cnt) {
-            s_rect[tid] = rect[idx];
-            uint32_t id = order ? order[idx] : (uint32_t)idx, rank = 0;
-            if (depth && dr.key_bits) {
-                const uint32_t dmin = misc[NGS_MISC_DMIN], dmax = misc[NGS_MISC_DMAX];
-                const uint32_t r = dr.rank(__float_as_uint(depth[idx]), dmin, dr.shift(dmin, dmax));
-                rank = dr.key_part(r);
-                id |= dr.word_part(r);
-            }
-            s_id[tid] = make_uint2(id, rank);
+        rc = rect[idx];
+        if (order) id = order[idx];
+        if (ranked) zbits = __float_as_uint(depth[idx]);
+    }
+    if (cnt) {
+        uint32_t rank = 0;
+        if (ranked) {
+            const uint32_t r = dr.rank(zbits, dmin, dr.shift(dmin, dmax));
+            rank = dr.key_part(r);
+            id |= dr.word_part(r);
         }
+        s_rect[tid] = rc;
+        s_id[tid] = make_uint2(id, rank);
     }
     const uint32_t incl = wave_incl_scan_u32(cnt, lane);
     s_incl[tid] = incl;
+    s_excl[tid] = incl - cnt;
     if (lane == 63) s_wave_tot[wave] = incl;
     __syncthreads();
-    uint32_t wave_base = block_offs[blockIdx.x];
+    uint32_t wave_base = block_base;
     for (int w = 0; w < wave; w++) wave_base += s_wave_tot[w];
     uint32_t wave_total = s_wave_tot[wave];
     if (wave_base + wave_total > capacity || wave_base + wave_total < wave_base) {  // wave-uniform
@@ -257,35 +268,38 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void duplicate_kernel(int P, const
         wave_total = wave_base < capacity ? capacity - wave_base : 0u;
     }
     const uint32_t* incl_w = s_incl + wave * 64;
-    for (uint32_t k = lane; k < wave_total; k += 64) {
-        // smallest j with incl_w[j] > k
-        int lo = 0, hi = 63;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (incl_w[mid] > k) hi = mid; else lo = mid + 1;
-        }
-        const int j = lo;
-        const uint32_t local = k - (j ? incl_w[j - 1] : 0u);
+    // The loop below is the whole kernel (one trip per 64 instances), and it is bound by the number of vector
+    // instructions it issues: nothing in it branches on a lane's values, and the store addresses advance as pointers.
+    uint32_t* kp = keys + (size_t)wave_base + lane;
+    uint32_t* vp = vals + (size_t)wave_base + lane;
+    for (uint32_t k = lane; k < wave_total; k += 64, kp += 64, vp += 64) {
+        // smallest j with incl_w[j] > k: six halving steps, always
+        int j = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) j += incl_w[j + step - 1] <= k ? step : 0;
+        const uint32_t local = k - s_excl[wave * 64 + j];
         const uint2 r = s_rect[wave * 64 + j];
         const uint32_t x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu;
         const uint32_t w = x1 - x0;
         // row and column of the local-th tile of the rectangle: local / w and local % w.  An integer division by a
-        // variable costs some 25 vector instructions; below 2^22 a float reciprocal is off by at most one.
-        uint32_t qy, qx;
-        if (local < (1u << 22)) {
-            qy = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)w));
-            qx = local - qy * w;
-            if ((int32_t)qx < 0) { qy--; qx += w; }
-            else if (qx >= w) { qy++; qx -= w; }
-        } else {
+        // variable costs some 25 vector instructions; below 2^22 a float reciprocal is off by at most one either way.
+        uint32_t qy = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)w));
+        uint32_t qx = local - qy * w;
+        const bool under = (int32_t)qx < 0;
+        qy -= under ? 1u : 0u;
+        qx += under ? w : 0u;
+        const bool over = qx >= w;
+        qy += over ? 1u : 0u;
+        qx -= over ? w : 0u;
+        if (__builtin_amdgcn_ballot_w64(local >= (1u << 22)) != 0ull) {  // wave-uniform; a rectangle of four million tiles
             qy = local / w;
             qx = local % w;
         }
         const uint32_t ty = y0 + qy, tx = x0 + qx;
         // the tile id above the high part of the depth rank (the low part rides in the list word)
         const uint2 ir = s_id[wave * 64 + j];
-        keys[(size_t)wave_base + k] = ((ty * (uint32_t)grid_x + tx) << dr.key_bits) | ir.y;
-        vals[(size_t)wave_base + k] = ir.x;
+        *kp = ((ty * (uint32_t)grid_x + tx) << dr.key_bits) | ir.y;
+        *vp = ir.x;
     }
 }
 
