@@ -50,9 +50,10 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
         "preprocess_fwd": P * (12 + 8) + vP * (32 + 12 * c + 49),
         "scan_block_sums": 8 * ((P + 255) // 256),
         # the tile-level sort moves (tile id, Gaussian index) pairs of 8 bytes; the depth joins in the per-tile sort
-        "duplicate_with_keys": 4 * P + 16 * vP + 8 * R,  # tile count; rectangle, offset share and depth; key + list word
+        # tile count; rectangle, offset share and depth; key + list word; the tile ranges zeroed on the side
+        "duplicate_with_keys": 4 * P + 16 * vP + 8 * R + 8 * T,
         "radix_sort_tile_bits": tile_passes * 16 * R,
-        "tile_ranges": 4 * R + 16 * T,
+        "tile_ranges": 4 * R + 8 * T,
         # list words and keys in (both carry the depth rank, so no depth is gathered), list out
         "segment_sort_depth": 4 * R + 4 * R + 4 * R + 8 * T,
         # four 8-bit passes over P (depth bits, index) pairs (histogram read + pair read + pair write), then the
