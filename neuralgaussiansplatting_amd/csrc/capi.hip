@@ -308,12 +308,33 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     const int nblocks = (P + NGS_GAUSS_BLOCK - 1) / NGS_GAUSS_BLOCK;
     static_assert(32 / 8 % 2 == 0, "an even number of depth passes: the unsorted input goes to buffer 0");
 
+    // Where the depth order comes from (both give the same lists): a sort of the P Gaussians before their instances
+    // are emitted -- 14 small launches whose cost follows P -- or a sort of every tile's list afterwards -- two
+    // launches whose cost follows the instance count and rises steeply once lists outgrow a workgroup (4096
+    // entries).  Measured on MI355X the first costs about 50 us + 45 us per million Gaussians, the second about
+    // 12 us + 6 us per million instances while no list passes 4096 entries and the instances carry their depth rank
+    // (0.085 ms at 1500 per tile on average and 12 M instances), rising steeply where the longest lists do (2900 per
+    // tile on average and 24 M instances).
+    const int T = cam.grid_x * cam.grid_y;
+    auto sort_gaussians_first = [&](int64_t instances) {
+        if (g_depth_order_choice >= 0) return g_depth_order_choice == 1;
+        const double inst = (double)instances, per_tile = inst / (double)T;
+        const double by_tile = 12.0 + 6.1e-6 * inst * (per_tile > 2600.0 ? 1.0 + (per_tile - 2600.0) / 150.0 : 1.0);
+        const double by_gaussian = 50.0 + 45e-6 * (double)P;
+        return by_gaussian < by_tile;
+    };
+    int64_t capacity = binning_capacity > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)binning_capacity;
+    // With a capacity from the caller the choice is made now, and a frame that takes the per-tile sort does not write
+    // the Gaussian-level sort's input (8 bytes per Gaussian).
+    const bool sort_input = capacity == 0 || sort_gaussians_first(capacity);
+
     const int ps = prof_acquire();
     NGS_HIP(hipMemsetAsync(misc, 0, 32, st));
     prof_begin(ps, ST_PREPROCESS, st);
     ngs_launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, raw, shs,
                               cov3D_precomp, colors_precomp, cam, prefiltered, radii, rec, depth, rect, tiles, clamped,
-                              block_sums, (uint32_t*)(gb + gl.block_depths), misc, dkeys[0], order[0]);
+                              block_sums, (uint32_t*)(gb + gl.block_depths), misc, sort_input ? dkeys[0] : nullptr,
+                              sort_input ? order[0] : nullptr);
     prof_end(ps, ST_PREPROCESS, st);
     NGS_STAGE("preprocess");
     prof_begin(ps, ST_SCAN, st);
@@ -342,32 +363,19 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         if ((host_misc[1] & 2u) || host_misc[0] > 0x7fffffffu) return fail(fn, "more than 2^31-1 tile instances");
         return 0;
     };
-    int64_t capacity = binning_capacity > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)binning_capacity;
+    const bool early_choice = capacity != 0;
     if (capacity == 0) {
         if (learn_count()) return 1;
         capacity = (int64_t)host_misc[0];
     }
 
-    const int T = cam.grid_x * cam.grid_y;
     const int tile_bits = (int)higher_msb((uint32_t)T);
     const int in_buf = ngs_sort_input_buffer(tile_bits);
     uint2* ranges = (uint2*)(ib + il.ranges);
     const size_t ranges_clear = il.hard + 16 - il.ranges;  // the ranges and, behind them, the work lists' counters
-    // Where the depth order comes from (both give the same lists): a sort of the P Gaussians before their instances
-    // are emitted -- 14 small launches whose cost follows P -- or a sort of every tile's list afterwards -- two
-    // launches whose cost follows the instance count and rises steeply once lists outgrow a workgroup (4096
-    // entries).  Measured on MI355X the first costs about 50 us + 45 us per million Gaussians, the second about
-    // 12 us + 6 us per million instances while no list passes 4096 entries and the instances carry their depth rank
-    // (0.085 ms at 1500 per tile on average and 12 M instances), rising steeply where the longest lists do (2900 per
-    // tile on average and 24 M instances).
-    bool depth_first;
-    {
-        const double inst = (double)capacity, per_tile = inst / (double)T;
-        const double by_tile = 12.0 + 6.1e-6 * inst * (per_tile > 2600.0 ? 1.0 + (per_tile - 2600.0) / 150.0 : 1.0);
-        const double by_gaussian = 50.0 + 45e-6 * (double)P;
-        depth_first = by_gaussian < by_tile;
-        if (g_depth_order_choice >= 0) depth_first = g_depth_order_choice == 1;
-    }
+    // (made before the first kernel when the caller gave a capacity: the choice must not change once the per-Gaussian
+    // kernel has or has not written the Gaussian-level sort's input)
+    const bool depth_first = early_choice ? sort_input : sort_gaussians_first(capacity);
     // Instances emitted in index order carry a depth rank beside the tile id of their key and the Gaussian index of
     // their list word, so that the per-tile sort reads it with the list instead of gathering a depth per entry.
     DepthRank dr = ngs_depth_rank(P, tile_bits, !depth_first && g_depth_order_choice != 3);

@@ -286,7 +286,8 @@ struct GeoAdamArgs {
 int ngs_set_error(const char* what, const char* detail);
 void ngs_clear_error(void);
 // preprocess_fwd.hip
-// dkeys / order: depth bits (all ones when culled) and the Gaussian's own index, the input of the depth sort
+// dkeys / order: depth bits (all ones when culled) and the Gaussian's own index, the input of the depth sort (both NULL:
+// not written, for a frame that is known to take the per-tile sort)
 // raw != 0: scales, rots and opac are the optimiser's raw parameters; the kernel applies exp / normalise / sigmoid
 void ngs_launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* means, const float* scales, float mod,
                                const float* rots, const float* opac, int raw, const float* shs, const float* cov_pre,

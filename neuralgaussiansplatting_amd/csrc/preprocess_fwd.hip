@@ -250,8 +250,10 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
         tiles[idx] = my_tiles;
         // input of the depth sort: the bits of a positive float order like the float; a culled Gaussian emits no
         // instance, so its place in the order does not matter -- it goes to the end
-        dkeys[idx] = live ? __float_as_uint(view_z) : 0xffffffffu;
-        order[idx] = (uint32_t)idx;
+        if (dkeys) {
+            dkeys[idx] = live ? __float_as_uint(view_z) : 0xffffffffu;
+            order[idx] = (uint32_t)idx;
+        }
     }
     if (EAGER) {
         // records of the wave's visible Gaussians: 4 KiB contiguous per wave (a culled Gaussian's record is never
