@@ -79,7 +79,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
     const int hi = min(n, lo + per);
     const bool in_regs = groups <= SCAN_REGS;
     __shared__ unsigned long long wave_wide[SCAN_THREADS / 64];
-    uint32_t s = 0;
+    uint32_t s = 0, marks = 0;
     unsigned long long wide = 0;  // the same sum without wrap-around, to notice a count that does not fit
     uint4 held[SCAN_REGS];
     if (in_regs) {
@@ -99,31 +99,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
         }
 #pragma unroll
         for (int j = 0; j < SCAN_REGS; j++) {
+            // the top bit of an entry is not part of the count: preprocess_fwd's "culled although prefiltered" mark
+            marks |= held[j].x | held[j].y | held[j].z | held[j].w;
+            held[j].x &= 0x7fffffffu; held[j].y &= 0x7fffffffu; held[j].z &= 0x7fffffffu; held[j].w &= 0x7fffffffu;
             s += held[j].x + held[j].y + held[j].z + held[j].w;
             wide += (unsigned long long)held[j].x + held[j].y + held[j].z + held[j].w;
         }
     } else {
         for (int i = lo; i < hi; i++) {
-            s += in[i];
-            wide += in[i];
+            marks |= in[i];
+            s += in[i] & 0x7fffffffu;
+            wide += in[i] & 0x7fffffffu;
         }
     }
+    const bool marked = __ballot((marks & 0x80000000u) != 0u) != 0ull;  // wave-uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t incl = wave_incl_scan_u32(s, lane);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wide += __shfl_xor(wide, o);
+    __shared__ uint32_t wave_marked[SCAN_THREADS / 64];
     if (lane == 63) {
         wave_tot[wave] = incl;
         wave_wide[wave] = wide;
+        wave_marked[wave] = marked ? 1u : 0u;
     }
     __syncthreads();
-    uint32_t base = 0, total = 0;
+    uint32_t base = 0, total = 0, flags = 0;
     unsigned long long total_wide = 0;
     for (int w = 0; w < SCAN_THREADS / 64; w++) {
         const uint32_t t = wave_tot[w];
         if (w < wave) base += t;
         total += t;
         total_wide += wave_wide[w];
+        flags |= wave_marked[w];  // error flag 1: a point was culled although the caller said they were prefiltered
     }
     uint32_t run = base + incl - s;
     if (in_regs) {
@@ -147,21 +155,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
         }
     } else {
         for (int i = lo; i < hi; i++) {
-            const uint32_t v = in[i];
+            const uint32_t v = in[i] & 0x7fffffffu;
             out[i] = run;
             run += v;
         }
     }
     if (threadIdx.x == 0 && misc) {  // misc == NULL: a scan of offsets only (the count has been posted before)
         if (total_wide > 0x7fffffffull) {  // the count is handed on as a signed 32-bit number
-            misc[1] |= 2u;
+            flags |= 2u;
             total = 0xffffffffu;
         }
         misc[0] = total;
+        misc[1] = flags;  // written, not merged: nobody has to clear the word before a frame
         // The host is spinning on this word of pinned host memory (it holds ~0 until now): the instance count and
         // the error flag reach it without a copy engine or an interrupt in between.
         if (mailbox)
-            __hip_atomic_store(mailbox, ((unsigned long long)misc[1] << 32) | total, __ATOMIC_RELEASE,
+            __hip_atomic_store(mailbox, ((unsigned long long)flags << 32) | total, __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

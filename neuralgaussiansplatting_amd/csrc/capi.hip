@@ -329,7 +329,6 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     const bool sort_input = capacity == 0 || sort_gaussians_first(capacity);
 
     const int ps = prof_acquire();
-    NGS_HIP(hipMemsetAsync(misc, 0, 32, st));
     prof_begin(ps, ST_PREPROCESS, st);
     ngs_launch_preprocess_fwd(st, P, D, M, means3D, scales, scale_modifier, rotations, opacities, raw, shs,
                               cov3D_precomp, colors_precomp, cam, prefiltered, radii, rec, depth, rect, tiles, clamped,

@@ -44,7 +44,8 @@ struct GeomLayout {
     size_t tiles;      // u32   [P]  tiles touched
     size_t radii;      // i32   [P]  internal radii when the caller passes none
     size_t clamped;    // u8    [P]  bit ch set when colour channel ch was clamped at 0
-    size_t block_sums; // u32   [ceil(P/256)] tiles touched per 256-Gaussian block
+    size_t block_sums; // u32   [ceil(P/256)] tiles touched per 256-Gaussian block (top bit: a point of the block was culled
+                       //            although the caller said the points were prefiltered)
     size_t block_offs; // u32   [ceil(P/256)] exclusive prefix of block_sums
     size_t misc;       // u32   [8]  [0] total instances R, [1] error flags (1 prefiltered point culled, 2 count
                        //            beyond 2^31-1, 4 count beyond the binning buffer's capacity), [2] / [3] a lower /

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     __shared__ float4 s_sh[EAGER ? (NGS_GAUSS_BLOCK / 64) * SH_WAVE_F4 : 1];
     const int idx = blockIdx.x * NGS_GAUSS_BLOCK + threadIdx.x;
     uint32_t my_tiles = 0;
+    bool filtered_anyway = false;  // culled by the depth test although the caller said the points were prefiltered
     int my_radius = 0;
     float4 ld[EAGER ? 12 : 1];  // this lane's share of the wave's SH rows on their way to LDS
     float4* const wslots = s_sh + (EAGER ? (threadIdx.x >> 6) * SH_WAVE_F4 : 0);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
             // The reference aborts the kernel here when `prefiltered` is set
             // (auxiliary.h:156-160); this library raises an error flag that the
             // host turns into an error return instead of faulting the GPU.
-            if (prefiltered) misc[1] = 1u;
+            filtered_anyway = prefiltered != 0;
         } else {
             const float4 ph = xform44(px, py, pz, proj);
             const float pw = 1.0f / (ph.w + 0.0000001f);
@@ -268,7 +269,9 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
         }
     }
     // Tiles touched by this block of 256 Gaussians: the first level of the instance-offset scan.
-    const uint32_t ws = wave_sum_u32(my_tiles);
+    // (the top bit of a wave's or a block's count says that one of its points was culled although prefiltered was
+    // set; the scan kernel turns it into the error flag, so that no word has to be cleared before this kernel runs)
+    const uint32_t ws = min(wave_sum_u32(my_tiles), 0x7fffffffu) | (__ballot(filtered_anyway) != 0ull ? 0x80000000u : 0u);
     // Depth extremes of the block's visible Gaussians: the frame's extremes fix the scale of the depth rank that
     // rides in the instances' sort keys.
     uint32_t dlo = live ? __float_as_uint(view_z) : 0xffffffffu, dhi = live ? __float_as_uint(view_z) : 0u;
@@ -284,14 +287,15 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t sum = 0, blo = 0xffffffffu, bhi = 0u;
+        uint32_t sum = 0, flag = 0, blo = 0xffffffffu, bhi = 0u;
 #pragma unroll
         for (int w = 0; w < NGS_GAUSS_BLOCK / 64; w++) {
-            sum += wave_tot[w];
+            sum += wave_tot[w] & 0x7fffffffu;
+            flag |= wave_tot[w] & 0x80000000u;
             blo = min(blo, wave_dmin[w]);
             bhi = max(bhi, wave_dmax[w]);
         }
-        block_sums[blockIdx.x] = sum;
+        block_sums[blockIdx.x] = min(sum, 0x7fffffffu) | flag;
         // bounds, 16 bits each: the smallest depth's high half, and the largest's plus one (a visible depth is a
         // positive finite float, so that still fits); 0xffff and 0 for a block without a visible Gaussian
         block_depths[blockIdx.x] = (blo >> 16) | (bhi ? min((bhi >> 16) + 1u, 0xffffu) << 16 : 0u);
