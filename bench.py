@@ -12,6 +12,9 @@ inputs already resident in HBM; with N > 1 each rank renders its own view of
 the replicated scene and the step ends with the exchange (RCCL) that leaves the
 sum over views of the per-Gaussian gradients on every rank (see
 neuralgaussiansplatting_amd/view_parallel.py).  Rank 0 prints one JSON line.
+The timed loop of exactly --steps steps (barrier + device synchronisation on
+both sides, slowest rank) is run --repeats times; ``value`` and ``ms_per_step``
+are those of the median loop, ``repeats`` holds the minimum and maximum.
 
 Side loops reported in the same line: whole training iterations (at most 20 from the initial scene unless
 --train-steps says otherwise: fitting the random target changes the scene and with it the work per pixel), the
@@ -19,6 +22,7 @@ index-map operator and the nearest-neighbour initialisation.  Python's garbage c
 timed loops; its full collections take tens of milliseconds and would land in whichever loop is running.
 """
 import argparse
+import ctypes
 import gc
 import json
 import os
@@ -108,7 +112,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="c4", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--config", default="c4", choices=sorted(synthetic.CONFIGS) + sorted(synthetic.CLUSTERED_CONFIGS),
+                    help="c1..c5: uniform clouds of small splats; c4s: c4's counts with the shape of a trained scene "
+                         "(clustered positions, log-normal sizes, bimodal opacities)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed loop of --steps steps is run this many times; the line reports the median loop "
+                         "(value, ms_per_step) and the minimum / maximum beside it")
     ap.add_argument("--exchange", default="factored", choices=("factored", "dense"),
                     help="gradient exchange at N > 1: all-gather of masked colour gradients + all-reduce of the other "
                          "11 floats per Gaussian (default), or one dense all-reduce of all 59")
@@ -155,9 +164,15 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    P, W, H, D, M, ls, ext = synthetic.CONFIGS[args.config]
-    ls = (ls[0] + args.log_scale_offset, ls[1] + args.log_scale_offset)
-    scene_cpu = synthetic.make_scene(P, D, ls, ext, 1234, M)  # same seed everywhere: replicated parameters
+    # same seed everywhere: replicated parameters
+    if args.config in synthetic.CLUSTERED_CONFIGS:
+        P, W, H, D, M, mean, ext = synthetic.CLUSTERED_CONFIGS[args.config]
+        ls = (mean + args.log_scale_offset, 1.0)  # mean and sigma of the log-size
+        scene_cpu = synthetic.make_clustered_scene(P, D, ls[0], ls[1], ext, 1234, M)
+    else:
+        P, W, H, D, M, ls, ext = synthetic.CONFIGS[args.config]
+        ls = (ls[0] + args.log_scale_offset, ls[1] + args.log_scale_offset)
+        scene_cpu = synthetic.make_scene(P, D, ls, ext, 1234, M)
     scene = scene_cpu.to(dev)
     V = max(args.views_per_gpu, 1)
     # orbit views: rank r renders views r*V .. r*V+V-1 of the orbit (view 0 of rank 0 is the single-GPU workload)
@@ -212,14 +227,44 @@ def main():
     vis = float((radii > 0).float().mean())
     # the headline loop runs without per-stage events; the stages are timed in a second, shorter loop
     _C.profile_enable(False)
-    with quiet_host():
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        elapsed = time.perf_counter() - t0
+    loops = []
+    for _ in range(max(args.repeats, 1)):
+        with quiet_host():
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            loops.append(time.perf_counter() - t0)
+    if world > 1:  # per loop, the slowest rank
+        t = torch.tensor(loops, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        loops = [float(v) for v in t.tolist()]
+    elapsed = sorted(loops)[len(loops) // 2]
     note("timed steps done")
+    # which of the two sources of the depth order the library took for this workload, and what the other one costs
+    depth_order = None
+    if world == 1 and V == 1 and not args.no_stage_timing:
+        L = _C.lib()
+        L.ngs_debug_depth_order_taken.restype = ctypes.c_int
+        taken = int(L.ngs_debug_depth_order_taken())
+        depth_order = {"taken": {0: "per-tile sort of the instances", 1: "sort of the Gaussians first"}.get(taken)}
+        for choice, key in ((0, "ms_per_step_per_tile_sort"), (1, "ms_per_step_gaussians_first")):
+            L.ngs_debug_depth_order(choice)
+            n = max(min(args.steps, 20), 1)
+            for _ in range(2):
+                step()
+            with quiet_host():
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    step()
+                fence()
+                depth_order[key] = round((time.perf_counter() - t0) / n * 1e3, 4)
+        L.ngs_debug_depth_order(-1)
+        for _ in range(2):  # the capacity estimate and the caches back to the automatic choice
+            step()
+        torch.cuda.synchronize(dev)
     stages = {}
     if not args.no_stage_timing:
         stage_steps = min(args.steps, 30) if args.stage_steps is None else args.stage_steps
@@ -232,10 +277,6 @@ def main():
         stages = _C.profile_read(reset=True)
         _C.profile_enable(False)
         note("stage timing done")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # ---- second loop: whole training iterations ----
     # The training loop fits a random target, which changes the scene (opacities fall, every pixel composites more
@@ -419,7 +460,12 @@ def main():
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "iters_per_s": round(world * V * args.steps / elapsed, 2),
+            "iters_per_s": round(args.steps / elapsed, 2), "views_per_s": round(world * V * args.steps / elapsed, 2),
+            "repeats": {"loops": len(loops), "steps_per_loop": args.steps, "reported": "median loop",
+                        "ms_per_step_min": round(min(loops) / args.steps * 1e3, 4),
+                        "ms_per_step_median": round(elapsed / args.steps * 1e3, 4),
+                        "ms_per_step_max": round(max(loops) / args.steps * 1e3, 4)},
+            "depth_order": depth_order,
             "config": {"workload": "%s%s: %d Gaussians, %dx%d, SH degree %d (M=%d), %s per GPU and step, "
                                    "fwd+bwd%s" % (args.config,
                                                   "" if args.log_scale_offset == 0.0 else

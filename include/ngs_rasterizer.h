@@ -411,10 +411,13 @@ int ngs_profile_read(double* total_ms, long long* launches, int reset);
  * tile-level sort; 1: always the depth sort of the Gaussians before their instances are emitted; 2 and 3: the
  * per-tile depth sort with the depth rank that instances carry through the tile-level sort made too coarse to stand
  * in for the depth (so that every depth is fetched after all), and with no rank carried at all.  The lists are the
- * same in every case.  Process-wide, not thread-safe.  No counterpart in the reference (which sorts all instances
- * on the full 64-bit key, rasterizer_impl.cu:303-308).
+ * same in every case.  The setting belongs to the calling thread (forward calls of other threads are not affected).
+ * ngs_debug_depth_order_taken returns what the calling thread's last forward call took (0 or 1; -1 before the
+ * first call).  No counterpart in the reference (which sorts all instances on the full 64-bit key,
+ * rasterizer_impl.cu:303-308).
  */
 void ngs_debug_depth_order(int choice);
+int ngs_debug_depth_order_taken(void);
 
 /* Message of the last failure on the calling thread ("" if none). */
 const char* ngs_last_error(void);

@@ -253,8 +253,11 @@ extern "C" int ngs_state_layout(int P, long long R, int W, int H, size_t* geomet
 // -1: the forward pass chooses where the depth order comes from; 0 / 1 force the per-tile sort / the sort of the
 // Gaussians; 2 / 3: the per-tile sort with a depth rank too coarse to stand in for the depth / with no rank at all
 // (tests and measurements; see ngs_debug_depth_order).
-static int g_depth_order_choice = -1;
+// Both are per calling thread.
+static thread_local int g_depth_order_choice = -1;
+static thread_local int g_depth_order_taken = -1;
 extern "C" void ngs_debug_depth_order(int choice) { g_depth_order_choice = choice; }
+extern "C" int ngs_debug_depth_order_taken(void) { return g_depth_order_taken; }
 
 static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
                         void* binning_ctx, ngs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
@@ -375,6 +378,7 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     // (made before the first kernel when the caller gave a capacity: the choice must not change once the per-Gaussian
     // kernel has or has not written the Gaussian-level sort's input)
     const bool depth_first = early_choice ? sort_input : sort_gaussians_first(capacity);
+    g_depth_order_taken = depth_first ? 1 : 0;
     // Instances emitted in index order carry a depth rank beside the tile id of their key and the Gaussian index of
     // their list word, so that the per-tile sort reads it with the list instead of gathering a depth per entry.
     DepthRank dr = ngs_depth_rank(P, tile_bits, !depth_first && g_depth_order_choice != 3);

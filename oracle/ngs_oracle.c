@@ -445,65 +445,71 @@ void ngs_oracle_render_forward(int W, int H, const uint32_t* ranges, const uint3
  * One tile of dgr/cuda_rasterizer/backward.cu:399-557: every pixel of the tile walks the tile's list back to front
  * and adds its terms to d_xy [P][3] (x,y used), d_conic [P][4] (slots 0,1,3), d_opac [P], d_col [P][3] with plain
  * additions, pixel after pixel (the reference's float-atomic order is unspecified).
+ * Generated twice: with float sums (the reference's arithmetic) and with double sums (every per-pixel term is
+ * still the reference's float32 value; only the running sums are wide), which tells the rounding of a long float32
+ * sum apart from an error in the terms.
  */
-static void render_backward_tile(int tile, int W, int H, int gx, const uint32_t* ranges, const uint32_t* plist,
-                                 const float* bg, const float* xy, const float* conic_o, const float* feat,
-                                 const float* final_T, const uint32_t* n_contrib, const float* dpix, float* d_xy,
-                                 float* d_conic, float* d_opac, float* d_col)
-{
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
-    int tx = tile % gx, ty = tile / gx;
-    uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
-    for (int ly = 0; ly < TILE_H; ly++)
-        for (int lx = 0; lx < TILE_W; lx++) {
-            int px = tx * TILE_W + lx, py = ty * TILE_H + ly;
-            if (px >= W || py >= H) continue;
-            size_t pid = (size_t)W * py + px;
-            const float T_final = final_T[pid];
-            float T = T_final;
-            uint32_t contributor = hi - lo;
-            const uint32_t last = n_contrib[pid];
-            float rec[3] = {0, 0, 0}, last_c[3] = {0, 0, 0}, last_a = 0, dp[3];
-            for (int ch = 0; ch < 3; ch++) dp[ch] = dpix[(size_t)ch * H * W + pid];
-            for (uint32_t k = hi; k-- > lo;) {
-                contributor--;
-                if (contributor >= last) continue;
-                uint32_t g = plist[k];
-                float dx = xy[2 * g] - (float)px, dy = xy[2 * g + 1] - (float)py;
-                const float* co = conic_o + 4 * g;
-                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                if (power > 0.0f) continue;
-                float G = expf(power);
-                float alpha = fminf(0.99f, co[3] * G);
-                if (alpha < 1.0f / 255.0f) continue;
-                T = T / (1.f - alpha);
-                float w = alpha * T;
-                float dL_da = 0.0f;
-                for (int ch = 0; ch < 3; ch++) {
-                    float c = feat[3 * g + ch];
-                    rec[ch] = last_a * last_c[ch] + (1.f - last_a) * rec[ch];
-                    last_c[ch] = c;
-                    dL_da += (c - rec[ch]) * dp[ch];
-                    d_col[3 * g + ch] += w * dp[ch];
-                }
-                dL_da *= T;
-                last_a = alpha;
-                float bgdot = 0;
-                for (int ch = 0; ch < 3; ch++) bgdot += bg[ch] * dp[ch];
-                dL_da += (-T_final / (1.f - alpha)) * bgdot;
-                float dL_dG = co[3] * dL_da;
-                float gdx = G * dx, gdy = G * dy;
-                float dG_dx = -gdx * co[0] - gdy * co[1];
-                float dG_dy = -gdy * co[2] - gdx * co[1];
-                d_xy[3 * g] += dL_dG * dG_dx * ddelx_dx;
-                d_xy[3 * g + 1] += dL_dG * dG_dy * ddely_dy;
-                d_conic[4 * g] += -0.5f * gdx * dx * dL_dG;
-                d_conic[4 * g + 1] += -0.5f * gdx * dy * dL_dG;
-                d_conic[4 * g + 3] += -0.5f * gdy * dy * dL_dG;
-                d_opac[g] += G * dL_da;
-            }
-        }
+#define RENDER_BACKWARD_TILE(NAME, ACC) \
+static void NAME(int tile, int W, int H, int gx, const uint32_t* ranges, const uint32_t* plist, \
+                 const float* bg, const float* xy, const float* conic_o, const float* feat, \
+                 const float* final_T, const uint32_t* n_contrib, const float* dpix, ACC* d_xy, \
+                 ACC* d_conic, ACC* d_opac, ACC* d_col) \
+{ \
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H); \
+    int tx = tile % gx, ty = tile / gx; \
+    uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1]; \
+    for (int ly = 0; ly < TILE_H; ly++) \
+        for (int lx = 0; lx < TILE_W; lx++) { \
+            int px = tx * TILE_W + lx, py = ty * TILE_H + ly; \
+            if (px >= W || py >= H) continue; \
+            size_t pid = (size_t)W * py + px; \
+            const float T_final = final_T[pid]; \
+            float T = T_final; \
+            uint32_t contributor = hi - lo; \
+            const uint32_t last = n_contrib[pid]; \
+            float rec[3] = {0, 0, 0}, last_c[3] = {0, 0, 0}, last_a = 0, dp[3]; \
+            for (int ch = 0; ch < 3; ch++) dp[ch] = dpix[(size_t)ch * H * W + pid]; \
+            for (uint32_t k = hi; k-- > lo;) { \
+                contributor--; \
+                if (contributor >= last) continue; \
+                uint32_t g = plist[k]; \
+                float dx = xy[2 * g] - (float)px, dy = xy[2 * g + 1] - (float)py; \
+                const float* co = conic_o + 4 * g; \
+                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy; \
+                if (power > 0.0f) continue; \
+                float G = expf(power); \
+                float alpha = fminf(0.99f, co[3] * G); \
+                if (alpha < 1.0f / 255.0f) continue; \
+                T = T / (1.f - alpha); \
+                float w = alpha * T; \
+                float dL_da = 0.0f; \
+                for (int ch = 0; ch < 3; ch++) { \
+                    float c = feat[3 * g + ch]; \
+                    rec[ch] = last_a * last_c[ch] + (1.f - last_a) * rec[ch]; \
+                    last_c[ch] = c; \
+                    dL_da += (c - rec[ch]) * dp[ch]; \
+                    d_col[3 * g + ch] += w * dp[ch]; \
+                } \
+                dL_da *= T; \
+                last_a = alpha; \
+                float bgdot = 0; \
+                for (int ch = 0; ch < 3; ch++) bgdot += bg[ch] * dp[ch]; \
+                dL_da += (-T_final / (1.f - alpha)) * bgdot; \
+                float dL_dG = co[3] * dL_da; \
+                float gdx = G * dx, gdy = G * dy; \
+                float dG_dx = -gdx * co[0] - gdy * co[1]; \
+                float dG_dy = -gdy * co[2] - gdx * co[1]; \
+                d_xy[3 * g] += dL_dG * dG_dx * ddelx_dx; \
+                d_xy[3 * g + 1] += dL_dG * dG_dy * ddely_dy; \
+                d_conic[4 * g] += -0.5f * gdx * dx * dL_dG; \
+                d_conic[4 * g + 1] += -0.5f * gdx * dy * dL_dG; \
+                d_conic[4 * g + 3] += -0.5f * gdy * dy * dL_dG; \
+                d_opac[g] += G * dL_da; \
+            } \
+        } \
 }
+RENDER_BACKWARD_TILE(render_backward_tile, float)
+RENDER_BACKWARD_TILE(render_backward_tile_wide, double)
 
 /*
  * dgr/cuda_rasterizer/backward.cu:399-557 over all tiles.  Accumulates into the outputs (callers zero them).
@@ -554,6 +560,55 @@ int ngs_oracle_render_backward(int P, int W, int H, const uint32_t* ranges, cons
             d_opac[i] += base[(size_t)7 * P + i];
             for (int k = 0; k < 3; k++) d_col[3 * i + k] += base[(size_t)8 * P + 3 * (size_t)i + k];
         }
+    free(priv);
+    return 0;
+}
+
+/*
+ * The same sums held in double precision (per-thread private copies, summed in thread order, rounded to float at the
+ * end).  Not the reference's arithmetic: a yardstick for how far a float32 sum of up to a million terms -- in the
+ * reference's order or any other -- sits from the exact sum of the same terms.
+ */
+int ngs_oracle_render_backward_wide(int P, int W, int H, const uint32_t* ranges, const uint32_t* plist,
+                                    const float* bg, const float* xy, const float* conic_o, const float* feat,
+                                    const float* final_T, const uint32_t* n_contrib, const float* dpix, float* d_xy,
+                                    float* d_conic, float* d_opac, float* d_col)
+{
+    const int gx = (W + TILE_W - 1) / TILE_W, gy = (H + TILE_H - 1) / TILE_H;
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+#endif
+    const size_t per = (size_t)11 * (size_t)P;
+    double* priv = (double*)calloc((size_t)threads * per, sizeof(double));
+    if (!priv) return 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int me = 0;
+#ifdef _OPENMP
+        me = omp_get_thread_num();
+#endif
+        double* base = priv + (size_t)me * per;
+#pragma omp for schedule(dynamic, 1)
+        for (int tile = 0; tile < gx * gy; tile++)
+            render_backward_tile_wide(tile, W, H, gx, ranges, plist, bg, xy, conic_o, feat, final_T, n_contrib, dpix,
+                                      base, base + (size_t)3 * P, base + (size_t)7 * P, base + (size_t)8 * P);
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        double acc[11] = {0};
+        for (int t = 0; t < threads; t++) {
+            const double* base = priv + (size_t)t * per;
+            for (int k = 0; k < 3; k++) acc[k] += base[3 * (size_t)i + k];
+            for (int k = 0; k < 4; k++) acc[3 + k] += base[(size_t)3 * P + 4 * (size_t)i + k];
+            acc[7] += base[(size_t)7 * P + i];
+            for (int k = 0; k < 3; k++) acc[8 + k] += base[(size_t)8 * P + 3 * (size_t)i + k];
+        }
+        for (int k = 0; k < 3; k++) d_xy[3 * i + k] += (float)acc[k];
+        for (int k = 0; k < 4; k++) d_conic[4 * i + k] += (float)acc[3 + k];
+        d_opac[i] += (float)acc[7];
+        for (int k = 0; k < 3; k++) d_col[3 * i + k] += (float)acc[8 + k];
+    }
     free(priv);
     return 0;
 }
@@ -744,6 +799,23 @@ static void cov3d_backward(const float* s_in, float mod, const float* q, const f
     d_rot[1] = 2 * y * (dMt.c[1][0] + dMt.c[0][1]) + 2 * z * (dMt.c[2][0] + dMt.c[0][2]) + 2 * r * (dMt.c[1][2] - dMt.c[2][1]) - 4 * x * (dMt.c[2][2] + dMt.c[1][1]);
     d_rot[2] = 2 * x * (dMt.c[1][0] + dMt.c[0][1]) + 2 * r * (dMt.c[2][0] - dMt.c[0][2]) + 2 * z * (dMt.c[1][2] + dMt.c[2][1]) - 4 * y * (dMt.c[2][2] + dMt.c[0][0]);
     d_rot[3] = 2 * r * (dMt.c[0][1] - dMt.c[1][0]) + 2 * x * (dMt.c[2][0] + dMt.c[0][2]) + 2 * y * (dMt.c[1][2] + dMt.c[2][1]) - 4 * z * (dMt.c[1][1] + dMt.c[0][0]);
+}
+
+/*
+ * The 3D-covariance stage on its own, forward (dgr/cuda_rasterizer/forward.cu:118-152) and backward
+ * (backward.cu:278-341).  Exist so that this stage can be compared with what the reference's Python
+ * build_covariance_from_scaling_rotation (scene/gaussian_model.py:29-33) yields, also under autograd.
+ */
+void ngs_oracle_cov3d(int P, const float* scales, float mod, const float* rots, float* cov6)
+{
+    for (int i = 0; i < P; i++) cov3d_from_scale_rot(scales + 3 * i, mod, rots + 4 * i, cov6 + 6 * i);
+}
+
+void ngs_oracle_cov3d_backward(int P, const float* scales, float mod, const float* rots, const float* d_cov,
+                               float* d_scale, float* d_rot)
+{
+    for (int i = 0; i < P; i++)
+        cov3d_backward(scales + 3 * i, mod, rots + 4 * i, d_cov + 6 * i, d_scale + 3 * i, d_rot + 4 * i);
 }
 
 /*

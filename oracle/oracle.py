@@ -36,6 +36,7 @@ def lib():
         _lib.ngs_oracle_threads.restype = ctypes.c_int
         _lib.ngs_oracle_preprocess.restype = ctypes.c_int
         _lib.ngs_oracle_render_backward.restype = ctypes.c_int
+        _lib.ngs_oracle_render_backward_wide.restype = ctypes.c_int
         _lib.ngs_oracle_idxmap_forward.restype = ctypes.c_longlong
     return _lib
 
@@ -83,6 +84,26 @@ def sh_backward(deg, means3D, campos, shs, clamped, dL_dcolor):
     lib().ngs_oracle_sh_backward(P, int(deg), M, _p(means3D), _p(campos), _p(shs), _p(clamped), _p(dL_dcolor),
                                  _p(d_means), _p(d_sh))
     return d_sh, d_means
+
+
+def cov3d(scales, rotations, scale_modifier=1.0):
+    """[P,6] upper triangle of the 3D covariance, the covariance stage of the forward pass alone."""
+    scales, rotations = _f32(scales), _f32(rotations)
+    P = scales.shape[0]
+    out = np.zeros((P, 6), np.float32)
+    lib().ngs_oracle_cov3d(P, _p(scales), ctypes.c_float(scale_modifier), _p(rotations), _p(out))
+    return out
+
+
+def cov3d_backward(scales, rotations, dL_dcov3D, scale_modifier=1.0):
+    """(dL_dscales [P,3], dL_drotations [P,4]) of the covariance stage of the backward pass alone."""
+    scales, rotations, dL_dcov3D = _f32(scales), _f32(rotations), _f32(dL_dcov3D)
+    P = scales.shape[0]
+    d_s = np.zeros((P, 3), np.float32)
+    d_r = np.zeros((P, 4), np.float32)
+    lib().ngs_oracle_cov3d_backward(P, _p(scales), ctypes.c_float(scale_modifier), _p(rotations), _p(dL_dcov3D),
+                                    _p(d_s), _p(d_r))
+    return d_s, d_r
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
@@ -153,11 +174,14 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfov
 
 
 def backward(s, dL_dpix, means3D, viewmatrix, projmatrix, campos, bg, tanfovx, tanfovy, shs=None,
-             colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, stage1=None):
+             colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, stage1=None,
+             wide_sums=False):
     """Gradients in the layout of ``RasterizeGaussiansBackwardCUDA``
     (submodules/diff-gaussian-rasterization/rasterize_points.cu:151-159).
     ``stage1`` = dict(dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors) replaces the compositing stage's sums by the
-    given ones, so that the per-Gaussian chain after it can be compared on identical inputs."""
+    given ones, so that the per-Gaussian chain after it can be compared on identical inputs.  ``wide_sums`` holds the
+    compositing stage's running sums in double precision (same float32 terms): not the reference's arithmetic, a
+    yardstick for the rounding of long float32 sums."""
     L = lib()
     P, W, H, M, D = s["P"], s["W"], s["H"], s["M"], s["D"]
     means3D = _f32(means3D)
@@ -178,7 +202,8 @@ def backward(s, dL_dpix, means3D, viewmatrix, projmatrix, campos, bg, tanfovx, t
         for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors"):
             g[k][...] = np.asarray(stage1[k], np.float32).reshape(g[k].shape)
     else:
-        if L.ngs_oracle_render_backward(P, W, H, _p(s["ranges"]), _p(s["point_list"]), _p(bg), _p(s["means2D"]),
+        fn = L.ngs_oracle_render_backward_wide if wide_sums else L.ngs_oracle_render_backward
+        if fn(P, W, H, _p(s["ranges"]), _p(s["point_list"]), _p(bg), _p(s["means2D"]),
                                         _p(s["conic_opacity"]), _p(s["features"]), _p(s["final_T"]),
                                         _p(s["n_contrib"]), _p(dL_dpix), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]),
                                         _p(g["dL_dopacity"]), _p(g["dL_dcolors"])) != 0:

@@ -144,11 +144,85 @@ def lr_fixture():
              delayed=np.array([f2(int(s)) for s in steps]))
 
 
+class _zeros_on_cpu:
+    """utils/general_utils.py:65,83,102 allocate their results with ``torch.zeros(..., device="cuda")``; there is no
+    GPU where the fixtures are made, so for the duration of a call that one argument is redirected to the CPU.
+    The arithmetic of the reference's functions is untouched."""
+
+    def __enter__(self):
+        self._zeros = torch.zeros
+
+        def zeros(*a, **k):
+            if str(k.get("device", "cpu")).startswith("cuda"):
+                k["device"] = "cpu"
+            return self._zeros(*a, **k)
+
+        torch.zeros = zeros
+
+    def __exit__(self, *exc):
+        torch.zeros = self._zeros
+
+
+def cov3d_fixture():
+    """3D covariance from scale and rotation as the reference's ``compute_cov3D_python`` branch computes it
+    (gaussian_renderer/__init__.py:63-64 -> scene/gaussian_model.py:29-33 -> utils/general_utils.py:64-110), and its
+    derivatives under autograd.  This is what cuda_rasterizer/forward.cu:118-152 and backward.cu:278-341 restate.
+
+    Stored per scale modifier: cov [P,6]; for a fixed dL/dcov the gradients dL/dscale and dL/drot; and the same
+    map in factored form -- jac_s[p, j, k] = d cov[p, k] / d scale[p, j], jac_r[p, j, k] = d cov[p, k] / d rot[p, j]
+    -- so that a test can apply it to the dL/dcov a GPU run produces.
+
+    The reference's Python normalises the quaternion inside build_rotation, the kernel uses it as given; with unit
+    quaternions as input the covariances agree, and the Python's rotation gradient is the kernel's with its
+    component along the quaternion removed (the Jacobian of the normalisation at a unit quaternion is I - q q^T).
+    That component never reaches a parameter: render() feeds normalize(_rotation), whose backward removes it too."""
+    from utils.general_utils import build_scaling_rotation, strip_symmetric
+
+    def build_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):  # scene/gaussian_model.py:29-33
+        L = build_scaling_rotation(scaling_modifier * scaling, rotation)
+        actual_covariance = L @ L.transpose(1, 2)
+        return strip_symmetric(actual_covariance)
+
+    g = torch.Generator().manual_seed(777)
+    P = 211
+    scales0 = torch.exp(torch.rand(P, 3, generator=g) * 5.0 - 5.5)  # 0.004 .. 0.6, axis ratios up to ~150
+    rots0 = torch.nn.functional.normalize(torch.randn(P, 4, generator=g))
+    rots0[0] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    rots0[1] = torch.tensor([0.0, 1.0, 0.0, 0.0])
+    dL_dcov = torch.randn(P, 6, generator=g)
+    out = {"scales": scales0.numpy(), "rotations": rots0.numpy(), "dL_dcov": dL_dcov.numpy(),
+           "modifiers": np.array([1.0, 0.6, 1.7], np.float32)}
+    with _zeros_on_cpu():
+        for mi, mod in enumerate([1.0, 0.6, 1.7]):
+            s = scales0.clone().requires_grad_(True)
+            r = rots0.clone().requires_grad_(True)
+            cov = build_covariance_from_scaling_rotation(s, mod, r)
+            (cov * dL_dcov).sum().backward()
+            out["cov_m%d" % mi] = cov.detach().numpy()
+            out["dL_dscale_m%d" % mi] = s.grad.numpy()
+            out["dL_drot_m%d" % mi] = r.grad.numpy()
+            jac_s = np.zeros((P, 3, 6), np.float32)
+            jac_r = np.zeros((P, 4, 6), np.float32)
+            for k in range(6):
+                s2 = scales0.clone().requires_grad_(True)
+                r2 = rots0.clone().requires_grad_(True)
+                build_covariance_from_scaling_rotation(s2, mod, r2)[:, k].sum().backward()
+                jac_s[:, :, k] = s2.grad.numpy()
+                jac_r[:, :, k] = r2.grad.numpy()
+            out["jac_s_m%d" % mi] = jac_s
+            out["jac_r_m%d" % mi] = jac_r
+    np.savez(os.path.join(HERE, "cov3d.npz"), **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["cov3d"]:
+        cov3d_fixture()
+        sys.exit(0)
     sh_fixture()
     sh_backward_fixture()
     camera_fixture()
     loss_fixture()
     train_loss_fixture()
     lr_fixture()
+    cov3d_fixture()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

@@ -73,6 +73,66 @@ def test_python_sh_branch_gradients_match_reference(deg):
     np.testing.assert_allclose(got_means, want_means, rtol=0, atol=2e-6 * max(1.0, float(np.abs(want_means).max())))
 
 
+def cov3d_fixture_expectations(z, mi):
+    """What the kernel-side formulation must give for modifier ``mi`` of tests/golden/cov3d.npz, from the values the
+    reference's Python produced: (cov, dL_dscale, tangential dL_drot, jac_s, jac_r).  Two documented differences
+    between the reference's Python and its kernel are applied here, nowhere else: the kernel's dL_dscale is the
+    derivative with respect to (modifier * scale) -- backward.cu:318-320 does not multiply by the modifier -- so
+    the Python's is divided by it; and the Python normalises the quaternion, so its rotation gradient is the
+    kernel's with the component along the (unit) quaternion removed."""
+    mod = float(z["modifiers"][mi])
+    return (z["cov_m%d" % mi], z["dL_dscale_m%d" % mi] / mod, z["dL_drot_m%d" % mi], z["jac_s_m%d" % mi] / mod,
+            z["jac_r_m%d" % mi])
+
+
+def tangential(q, g):
+    return g - q * (q * g).sum(axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("mi", range(3))
+def test_cov3d_matches_reference_python_covariance(oracle, mi):
+    """The checker's 3D covariance (forward.cu:118-152) and its backward (backward.cu:278-341) against what the
+    reference's build_covariance_from_scaling_rotation (scene/gaussian_model.py:29-33 over
+    utils/general_utils.py:64-110, the function behind ``compute_cov3D_python``) gave, also under autograd
+    (fixture tests/golden/cov3d.npz, made by make_golden.py)."""
+    z = np.load(os.path.join(GOLD, "cov3d.npz"))
+    mod = float(z["modifiers"][mi])
+    want_cov, want_ds, want_dr, jac_s, jac_r = cov3d_fixture_expectations(z, mi)
+    q = z["rotations"]
+    cov = oracle.cov3d(z["scales"], q, mod)
+    np.testing.assert_allclose(cov, want_cov, rtol=0, atol=2e-6 * float(np.abs(want_cov).max()))
+    # per Gaussian as well: small splats are not hidden behind the largest one
+    per = np.abs(want_cov).max(axis=1, keepdims=True)
+    assert float((np.abs(cov - want_cov) / per).max()) < 4e-6
+    d_s, d_r = oracle.cov3d_backward(z["scales"], q, z["dL_dcov"], mod)
+    np.testing.assert_allclose(d_s, want_ds, rtol=0, atol=2e-6 * float(np.abs(want_ds).max()))
+    np.testing.assert_allclose(tangential(q, d_r), want_dr, rtol=0, atol=2e-6 * float(np.abs(want_dr).max()))
+    assert float(np.abs(want_dr).max()) > 0.1 and float(np.abs(want_ds).max()) > 0.1
+    # the factored form of the same map (what the GPU test applies to its own dL_dcov)
+    np.testing.assert_allclose(np.einsum("pjk,pk->pj", jac_s, z["dL_dcov"]), want_ds, rtol=0,
+                               atol=2e-6 * float(np.abs(want_ds).max()))
+    np.testing.assert_allclose(np.einsum("pjk,pk->pj", jac_r, z["dL_dcov"]), want_dr, rtol=0,
+                               atol=2e-6 * float(np.abs(want_dr).max()))
+
+
+@pytest.mark.parametrize("mi", range(3))
+def test_python_cov3d_branch_matches_reference(mi):
+    """render()'s compute_cov3D_python branch (this package's covariance_from_scaling_rotation, under autograd)
+    against the same fixture."""
+    from neuralgaussiansplatting_amd.gaussian_model import covariance_from_scaling_rotation
+    z = np.load(os.path.join(GOLD, "cov3d.npz"))
+    mod = float(z["modifiers"][mi])
+    s = torch.tensor(z["scales"], requires_grad=True)
+    r = torch.tensor(z["rotations"], requires_grad=True)
+    cov = covariance_from_scaling_rotation(s, mod, r)
+    (cov * torch.tensor(z["dL_dcov"])).sum().backward()
+    want = z["cov_m%d" % mi]
+    np.testing.assert_allclose(cov.detach().numpy(), want, rtol=0, atol=2e-6 * float(np.abs(want).max()))
+    ws, wr = z["dL_dscale_m%d" % mi], z["dL_drot_m%d" % mi]
+    np.testing.assert_allclose(s.grad.numpy(), ws, rtol=0, atol=2e-6 * float(np.abs(ws).max()))
+    np.testing.assert_allclose(r.grad.numpy(), wr, rtol=0, atol=2e-6 * float(np.abs(wr).max()))
+
+
 def test_camera_matrices_match_reference_graphics_utils():
     """Fixture made from utils/graphics_utils.py + the scene/cameras.py:54-57 recipe of the reference."""
     from neuralgaussiansplatting_amd.cameras import projection_matrix, world_to_view

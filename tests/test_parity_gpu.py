@@ -4,8 +4,12 @@ package, against the CPU checker on the same seeded inputs.
 Bar: integers derived on the per-Gaussian/binning path (radii, tiles touched,
 tile rectangles, sorted keys, point list, tile ranges, instance count) are
 bit-exact; rendered RGB is within 1e-5 abs; gradients of a loss with
-dL/dpixel ~ N(0,1)/(W*H) are within 1e-5 abs, and additionally within 2e-4 of
-each tensor's largest magnitude for an un-normalised dL/dpixel ~ N(0,1).
+dL/dpixel ~ N(0,1)/(W*H) are within 1e-5 abs.  For an un-normalised
+dL/dpixel ~ N(0,1): the BASELINE configurations at full size (c2..c5 and the
+trained-scene-like c4s) hold every gradient tensor within 5e-6 of its largest
+element with no absolute allowance (check_grads_full_size); the small cases
+and random sweeps use 2e-4 of the largest element plus a floor for tensors
+that are tiny throughout (check_grads).
 """
 import math
 import os
@@ -75,7 +79,28 @@ def run_hip(dgr, c, dL_dpix=None, colors_precomp=None, cov3D_precomp=None, scale
     return out
 
 
-def check_forward(o, h, exact_pixels=True):
+class KnifeEdge:
+    """Pixels where a splat fell on the other side of a threshold in the two implementations (alpha against 1/255,
+    transmittance against 1e-4): exp() differs by an ulp between libm and the GPU.  Truthy when there are any."""
+
+    def __init__(self, rgb_mask, contrib_mask):
+        self.rgb_mask, self.contrib_mask = rgb_mask, contrib_mask
+        self.rgb_pixels, self.contrib_pixels = int(rgb_mask.sum()), int(contrib_mask.sum())
+        self.count = self.rgb_pixels + self.contrib_pixels
+
+    def __bool__(self):
+        return self.count > 0
+
+    def gaussians(self, o):
+        """Indices of the Gaussians listed for the tiles that hold a flagged pixel."""
+        ys, xs = np.nonzero(self.rgb_mask | self.contrib_mask)
+        gx = (o["W"] + 15) // 16
+        tiles = np.unique((ys // 16) * gx + xs // 16)
+        parts = [o["point_list"][o["ranges"][t, 0]:o["ranges"][t, 1]] for t in tiles]
+        return np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.int64)
+
+
+def check_forward(o, h, exact_pixels=True, max_knife_edge=None):
     assert h["R"] == o["num_rendered"]
     np.testing.assert_array_equal(h["radii"], o["radii"])
     vis = o["radii"] > 0
@@ -94,19 +119,19 @@ def check_forward(o, h, exact_pixels=True):
         np.testing.assert_allclose(h["color"], o["out_color"], rtol=0, atol=RGB_ATOL)
         np.testing.assert_allclose(h["final_T"], o["final_T"], rtol=0, atol=RGB_ATOL)
         np.testing.assert_array_equal(h["n_contrib"], o["n_contrib"])
-    else:
-        # exp() differs by an ulp between libm and the GPU, so a splat whose alpha sits exactly on the 1/255
-        # threshold (or a pixel whose transmittance sits on the 1e-4 stop) may fall on either side: at most two
-        # such knife-edge pixels per image (2 per 100 000 pixels in large ones), each off by no more than that one
-        # splat's contribution
-        few = max(2, int(2e-5 * h["color"].shape[1] * h["color"].shape[2]))
-        off = (np.abs(h["color"] - o["out_color"]) > RGB_ATOL).any(axis=0) | (np.abs(h["final_T"] - o["final_T"]) > RGB_ATOL)
-        assert int(off.sum()) <= few, "%d pixels beyond %g" % (int(off.sum()), RGB_ATOL)
-        np.testing.assert_allclose(h["color"], o["out_color"], rtol=0, atol=2.0 / 255.0)
-        np.testing.assert_allclose(h["final_T"], o["final_T"], rtol=0, atol=1.0 / 255.0 + 1e-4)
-        assert int((h["n_contrib"] != o["n_contrib"]).sum()) <= few
-        return int(off.sum()) + int((h["n_contrib"] != o["n_contrib"]).sum())
-    return 0
+        return 0
+    # exp() differs by an ulp between libm and the GPU, so a splat whose alpha sits exactly on the 1/255
+    # threshold (or a pixel whose transmittance sits on the 1e-4 stop) may fall on either side: at most
+    # ``max_knife_edge`` such pixels per image (default: two, or 2 per 100 000 pixels in large ones), each off by
+    # no more than that one splat's contribution
+    few = max(2, int(2e-5 * h["color"].shape[1] * h["color"].shape[2])) if max_knife_edge is None else max_knife_edge
+    off = (np.abs(h["color"] - o["out_color"]) > RGB_ATOL).any(axis=0) | (np.abs(h["final_T"] - o["final_T"]) > RGB_ATOL)
+    edge = KnifeEdge(off, h["n_contrib"] != o["n_contrib"])
+    assert edge.rgb_pixels <= few, "%d pixels beyond %g" % (edge.rgb_pixels, RGB_ATOL)
+    np.testing.assert_allclose(h["color"], o["out_color"], rtol=0, atol=2.0 / 255.0)
+    np.testing.assert_allclose(h["final_T"], o["final_T"], rtol=0, atol=1.0 / 255.0 + 1e-4)
+    assert edge.contrib_pixels <= few, "%d pixels with another contributor count" % edge.contrib_pixels
+    return edge
 
 
 def check_grads(hg, og, scale=1.0, knife_edge_pixels=0):
@@ -127,6 +152,58 @@ def check_grads(hg, og, scale=1.0, knife_edge_pixels=0):
         # from dL_dconic to dL_dcov3D and on to scale and rotation amplifies it: factor 16)
         noise = max(GRAD_ATOL, 16.0 * 6e-8 * math.sqrt(scale)) if scale > 1.0 else GRAD_ATOL
         assert err / scale <= slack * max(GRAD_ATOL, noise * big / scale), "%s: abs err %g" % (name, err / scale)
+
+
+# The bar of the full-size configurations: every gradient tensor within this fraction of its largest element
+# (observed: at most 1e-6), with no absolute allowance; ten times that only on the rows of Gaussians that are
+# listed for a tile in which check_forward flagged a pixel.
+FULL_SIZE_GRAD_REL_TO_MAX = 5e-6
+
+
+def check_grads_full_size(hg, og, o, edge, W, H, bar=None):
+    bar = FULL_SIZE_GRAD_REL_TO_MAX if bar is None else bar
+    flagged = edge.gaussians(o) if edge else np.zeros(0, np.int64)
+    if edge:
+        edge.flagged = flagged
+    on_edge = np.zeros(o["P"], bool)
+    on_edge[flagged] = True
+    worst = {}
+    for name, ref in og.items():
+        got = hg[name].reshape(ref.shape)
+        big = float(np.abs(ref).max())
+        rows = np.abs(got - ref).reshape(ref.shape[0], -1).max(axis=1)
+        clean = float(rows[~on_edge].max()) if (~on_edge).any() else 0.0
+        edgy = float(rows[on_edge].max()) if on_edge.any() else 0.0
+        worst[name] = max(clean, edgy) / big
+        assert big > 0.0, name
+        assert clean <= bar * big, "%s: max err %g vs max magnitude %g (%.2e of it)" % (name, clean, big, clean / big)
+        assert edgy <= 10.0 * bar * big, "%s under knife-edge pixels: max err %g vs %g" % (name, edgy, big)
+        # the stated bar for a loss normalised by the pixel count, as the reference's is: 1e-5 absolute, relative to
+        # the tensor's largest element where that exceeds 1
+        assert max(clean, edgy) / (W * H) <= GRAD_ATOL * max(1.0, big / (W * H)), name
+    return worst
+
+
+def record_pixel_errors(config, W, H, R, edge, worst, bound):
+    """Appends a row to gpurun_out/r03_pixel_errors.md (the table kept under profiles/): how many pixels of a
+    full-size configuration differ from the checker by more than the bar, how many count another number of
+    contributors, and the largest gradient deviation as a fraction of each tensor's largest element."""
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "r03_pixel_errors.md")
+        new = not os.path.exists(path)
+        with open(path, "a") as f:
+            if new:
+                f.write("| config | pixels | instances | pixels with an RGB or final_T deviation > 1e-5 | pixels with another "
+                        "n_contrib | allowed (each) | Gaussians under such pixels | largest gradient deviation / "
+                        "largest element (tensor) |\n|---|---|---|---|---|---|---|---|\n")
+            name = max(worst, key=worst.get)
+            f.write("| %s | %d | %d | %d | %d | %d | %d | %.1e (%s) |\n" % (
+                config, W * H, R, edge.rgb_pixels if edge else 0, edge.contrib_pixels if edge else 0, bound,
+                len(edge.flagged) if edge else 0, worst[name], name))
+    except OSError:
+        pass
 
 
 STAGE1 = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors")
@@ -349,85 +426,85 @@ def test_debug_mode_same_result(dgr, oracle):
     check_forward(o, run_hip(dgr, c, debug=True))
 
 
-def test_config2_100k_800x800(dgr, oracle, depth_order):
-    """BASELINE configuration 2 at full size, per-pixel match."""
-    oracle.set_threads(8)
+# Most pixels of a full-size configuration that may sit on a threshold (deviation beyond the bar, or another
+# contributor count; each kind counted on its own): what two runs showed plus a half, see profiles/r03_pixel_errors.md
+MAX_KNIFE_EDGE = {"c2": 4, "c3": 4, "c4": 12, "c5": 12, "c4s": 12, "c4s_small": 4}
+
+
+# Scenes with splats hundreds of pixels wide: a Gaussian's gradient is a float32 sum of up to a million per-pixel terms,
+# and the checker's sum in the reference's order (one term after the other) is itself up to 1.2e-5 of the tensor's
+# largest element away from the exact sum of the same terms.  There the library is held to the tight bar against the
+# checker's sums kept in double precision, and to this one against the reference-order float32 sums.
+HEAVY_TAIL_REFERENCE_ORDER_BAR = 3e-5
+
+
+def full_size_parity(dgr, oracle, cfg, view=0, views=None, dL_seed=5, label=None, threads=8, heavy_tailed=False):
+    """Forward and backward of a BASELINE configuration at full size against the checker: integers bit-exact,
+    pixels within the bar except for a counted few on a threshold, every gradient tensor within
+    FULL_SIZE_GRAD_REL_TO_MAX of its largest element."""
+    from neuralgaussiansplatting_amd import synthetic
+    oracle.set_threads(min(threads, os.cpu_count() or 1))
     try:
-        from neuralgaussiansplatting_amd import synthetic
-        sc, W, H = synthetic.make_config("c2")
-        cam = synthetic.make_view(W, H, 0)
-        c = dict(scene=sc, cam=cam, W=W, H=H, D=0, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
+        sc, W, H = synthetic.make_config(cfg, seed=1234)
+        cam = synthetic.make_view(W, H, view) if views is None else synthetic.make_view(W, H, view, count=views)
+        c = dict(scene=sc, cam=cam, W=W, H=H, D=sc.sh_degree, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
                  tanfovy=math.tan(cam.FoVy * 0.5))
-        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(5))
+        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(dL_seed))
         o = oracle_forward(oracle, c)
-        assert 2.0 < o["num_rendered"] / 100_000 < 8.0
         h = run_hip(dgr, c, dL_dpix=dL)
-        edge = check_forward(o, h, exact_pixels=False)
-        oracle.set_threads(1)
+        edge = check_forward(o, h, exact_pixels=False, max_knife_edge=MAX_KNIFE_EDGE[cfg])
         og = oracle_backward(oracle, c, o, dL)
-        check_grads(h["grads"], og, scale=float(W * H), knife_edge_pixels=edge)
+        if heavy_tailed:
+            worst32 = check_grads_full_size(h["grads"], og, o, edge, W, H, bar=HEAVY_TAIL_REFERENCE_ORDER_BAR)
+            ogw = oracle_backward(oracle, c, o, dL, wide_sums=True)
+            worst = check_grads_full_size(h["grads"], ogw, o, edge, W, H)
+            k32 = max(worst32, key=worst32.get)
+            record_pixel_errors((label or cfg) + " vs the checker's sums in double precision", W, H, h["R"], edge,
+                                worst, MAX_KNIFE_EDGE[cfg])
+            record_pixel_errors((label or cfg) + " vs the checker's float32 sums in the reference's order", W, H,
+                                h["R"], edge, {k32: worst32[k32]}, MAX_KNIFE_EDGE[cfg])
+        else:
+            worst = check_grads_full_size(h["grads"], og, o, edge, W, H)
+            record_pixel_errors(label or cfg, W, H, h["R"], edge, worst, MAX_KNIFE_EDGE[cfg])
+        return c, dL, o, h
     finally:
         oracle.set_threads(1)
+
+
+def test_config2_100k_800x800(dgr, oracle, depth_order):
+    """BASELINE configuration 2 at full size, per-pixel match."""
+    c, dL, o, h = full_size_parity(dgr, oracle, "c2", label="c2 (%s)" % depth_order)
+    assert 2.0 < o["num_rendered"] / 100_000 < 8.0
 
 
 def test_config4_3m_1080p_full_size(dgr, oracle):
     """The headline configuration (3 M Gaussians, 1920x1080, SH degree 3) at full size: per-Gaussian integers,
     sorted keys, lists and ranges bit-exact, image and gradients within the bar, plus properties that do not need
     the checker (the sorted list is sorted, the ranges partition it, the backward pass is linear in dL/dpixel)."""
-    import os
-    from neuralgaussiansplatting_amd import synthetic
-    oracle.set_threads(min(16, os.cpu_count() or 1))
-    try:
-        sc, W, H = synthetic.make_config("c4", seed=1234)
-        cam = synthetic.make_view(W, H, 0)
-        c = dict(scene=sc, cam=cam, W=W, H=H, D=3, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
-                 tanfovy=math.tan(cam.FoVy * 0.5))
-        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(8))
-        o = oracle_forward(oracle, c)
-        h = run_hip(dgr, c, dL_dpix=dL)
-        assert h["R"] == o["num_rendered"] > 8_000_000
-        edge = check_forward(o, h, exact_pixels=False)
-        # properties of the binning state on their own
-        keys = h["keys_sorted"]
-        assert (keys[1:] >= keys[:-1]).all()
-        rng = h["ranges"].astype(np.int64)
-        nonempty = rng[:, 1] > rng[:, 0]
-        assert (rng[nonempty, 0][1:] == rng[nonempty, 1][:-1]).all()  # consecutive, no gaps, no overlap
-        assert rng[nonempty, 0][0] == 0 and rng[nonempty, 1][-1] == h["R"]
-        assert int(h["tiles_touched"].sum()) == h["R"]
-        og = oracle_backward(oracle, c, o, dL)
-        check_grads(h["grads"], og, scale=float(W * H), knife_edge_pixels=edge)
-        # linearity in dL/dpixel (float atomics reorder sums: tolerance, not equality)
-        h2 = run_hip(dgr, c, dL_dpix=2.0 * dL)
-        for name in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations"):
-            a, b = h["grads"][name], h2["grads"][name]
-            assert float(np.abs(b - 2.0 * a).max()) <= 1e-4 * float(np.abs(b).max()), name
-        # the forward pass is deterministic
-        assert np.array_equal(h["color"], h2["color"]) and np.array_equal(h["point_list"], h2["point_list"])
-    finally:
-        oracle.set_threads(1)
+    c, dL, o, h = full_size_parity(dgr, oracle, "c4", dL_seed=8, threads=16)
+    assert h["R"] == o["num_rendered"] > 8_000_000
+    # properties of the binning state on their own
+    keys = h["keys_sorted"]
+    assert (keys[1:] >= keys[:-1]).all()
+    rng = h["ranges"].astype(np.int64)
+    nonempty = rng[:, 1] > rng[:, 0]
+    assert (rng[nonempty, 0][1:] == rng[nonempty, 1][:-1]).all()  # consecutive, no gaps, no overlap
+    assert rng[nonempty, 0][0] == 0 and rng[nonempty, 1][-1] == h["R"]
+    assert int(h["tiles_touched"].sum()) == h["R"]
+    # linearity in dL/dpixel (float atomics reorder sums: tolerance, not equality)
+    h2 = run_hip(dgr, c, dL_dpix=2.0 * dL)
+    for name in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations"):
+        a, b = h["grads"][name], h2["grads"][name]
+        assert float(np.abs(b - 2.0 * a).max()) <= 4e-6 * float(np.abs(b).max()), name
+    # the forward pass is deterministic
+    assert np.array_equal(h["color"], h2["color"]) and np.array_equal(h["point_list"], h2["point_list"])
 
 
 def test_config3_300k_800x800_sh3(dgr, oracle):
     """BASELINE configuration 3 (300 k Gaussians, 800x800, SH degree 3; its training loop is covered by
     test_train_step_gpu.py::test_training_iterations_match_pytorch_assembly[c3]) at full size."""
-    oracle.set_threads(8)
-    try:
-        from neuralgaussiansplatting_amd import synthetic
-        sc, W, H = synthetic.make_config("c3")
-        cam = synthetic.make_view(W, H, 0)
-        c = dict(scene=sc, cam=cam, W=W, H=H, D=3, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
-                 tanfovy=math.tan(cam.FoVy * 0.5))
-        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(15))
-        o = oracle_forward(oracle, c)
-        assert 2.0 < o["num_rendered"] / 300_000 < 8.0
-        h = run_hip(dgr, c, dL_dpix=dL)
-        edge = check_forward(o, h, exact_pixels=False)
-        oracle.set_threads(1)
-        og = oracle_backward(oracle, c, o, dL)
-        check_grads(h["grads"], og, scale=float(W * H), knife_edge_pixels=edge)
-    finally:
-        oracle.set_threads(1)
+    c, dL, o, h = full_size_parity(dgr, oracle, "c3", dL_seed=15)
+    assert 2.0 < o["num_rendered"] / 300_000 < 8.0
 
 
 @pytest.mark.parametrize("view", [0, 5])
@@ -435,24 +512,31 @@ def test_config5_6m_1080p_one_view_per_gpu(view, dgr, oracle):
     """BASELINE configuration 5 is 6 M Gaussians at 1080p with eight orbit views, one per GPU: this is what each
     GPU computes, for two of the eight views, at full size (the exchange between GPUs is covered by
     test_view_parallel_gloo.py and the two-rank tests of test_train_step_gpu.py)."""
-    import os
-    from neuralgaussiansplatting_amd import synthetic
-    oracle.set_threads(min(16, os.cpu_count() or 1))
-    try:
-        sc, W, H = synthetic.make_config("c5", seed=1234)
-        cam = synthetic.make_view(W, H, view, count=8)
-        c = dict(scene=sc, cam=cam, W=W, H=H, D=3, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
-                 tanfovy=math.tan(cam.FoVy * 0.5))
-        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(20 + view))
-        o = oracle_forward(oracle, c)
-        h = run_hip(dgr, c, dL_dpix=dL)
-        assert h["R"] == o["num_rendered"] > 12_000_000
-        edge = check_forward(o, h, exact_pixels=False)
-        assert int(h["tiles_touched"].sum()) == h["R"]
-        og = oracle_backward(oracle, c, o, dL)
-        check_grads(h["grads"], og, scale=float(W * H), knife_edge_pixels=edge)
-    finally:
-        oracle.set_threads(1)
+    c, dL, o, h = full_size_parity(dgr, oracle, "c5", view=view, views=8, dL_seed=20 + view, label="c5 view %d" % view,
+                                   threads=16)
+    assert h["R"] == o["num_rendered"] > 12_000_000
+    assert int(h["tiles_touched"].sum()) == h["R"]
+
+
+def test_trained_scene_like_reduced_every_depth_order(dgr, oracle, depth_order):
+    """synthetic.make_clustered_scene at a reduced size (200 k Gaussians, 640x360): clustered positions, log-normal
+    sizes with splats hundreds of pixels wide, bimodal opacities -- tiles hold from a few hundred to nearly ten
+    thousand instances, so the short- and the long-list kernels of the per-tile sort both run in one frame; once
+    per way of obtaining the depth order."""
+    c, dL, o, h = full_size_parity(dgr, oracle, "c4s_small", dL_seed=31, label="c4s_small (%s)" % depth_order,
+                                   heavy_tailed=True)
+    per_tile = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert per_tile.max() > 4096 and per_tile.max() > 8 * np.median(per_tile)
+    assert o["radii"].max() > 200
+
+
+def test_trained_scene_like_3m_1080p_full_size(dgr, oracle):
+    """The headline configuration's counts and image size with the shape of a trained scene (``c4s``), at full
+    size, with the depth order taken from wherever the library chooses."""
+    c, dL, o, h = full_size_parity(dgr, oracle, "c4s", dL_seed=32, threads=16, heavy_tailed=True)
+    per_tile = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert h["R"] == o["num_rendered"] > 12_000_000 and per_tile.max() > 20_000
+    assert int(h["tiles_touched"].sum()) == h["R"]
 
 
 def test_closed_form_three_gaussian_scene(dgr):
@@ -519,6 +603,60 @@ def test_kernel_sh_backward_matches_reference_autograd_fixture(deg, dgr):
         assert not want_dir.any()
     else:
         assert float(np.abs(want_dir[use]).max()) > 1e-3
+
+
+@pytest.mark.parametrize("mi", range(3))
+def test_kernel_cov3d_matches_reference_python_fixture(mi, dgr):
+    """The covariance stage of the per-Gaussian kernels, forward and backward, against what the reference's
+    Python build_covariance_from_scaling_rotation gave, also under autograd (tests/golden/cov3d.npz, made by
+    tests/golden/make_golden.py from scene/gaussian_model.py:29-33 over utils/general_utils.py:64-110 -- the
+    function behind ``compute_cov3D_python``; kernel side: forward.cu:118-152, backward.cu:278-341).  Colours are
+    precomputed, so the covariance chain is the only per-Gaussian stage in play.
+      forward:  the run from (scale, rotation, modifier) equals the run fed the fixture's covariance;
+      backward: dL_dscales = jac_s . dL_dcov3D and the part of dL_drotations across the quaternion = jac_r . dL_dcov3D,
+                with dL_dcov3D the one this run produced."""
+    import os
+    from test_oracle_cpu import cov3d_fixture_expectations, tangential
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cov3d.npz"))
+    mod = float(z["modifiers"][mi])
+    want_cov, _, _, jac_s, jac_r = cov3d_fixture_expectations(z, mi)
+    P = z["scales"].shape[0]
+    c = case(P=P, W=128, H=96, D=0, seed=61, extent=(1.0, 0.8, 1.0))
+    sc = c["scene"]
+    sc.scales[:] = torch.tensor(z["scales"]) * 0.25  # the fixture's shapes, at a size that fits the picture
+    sc.rotations[:] = torch.tensor(z["rotations"])
+    cols = torch.rand(P, 3, generator=torch.Generator().manual_seed(9))
+    dL = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(10 + mi))
+    a = run_hip(dgr, c, dL_dpix=dL, colors_precomp=cols, scale_modifier=mod)
+    vis = a["radii"] > 0
+    assert vis.sum() > P // 2
+    # forward: the covariance is bilinear in the scale, so the fixture's covariance at a quarter of the scale is
+    # the fixture's / 16 exactly (a power of two)
+    cov = torch.tensor(want_cov / 16.0)
+    b = run_hip(dgr, c, dL_dpix=dL, colors_precomp=cols, cov3D_precomp=cov, scale_modifier=mod)
+    assert np.abs(a["radii"] - b["radii"]).max() <= 1
+    same = vis & (a["radii"] == b["radii"])
+    assert same.sum() >= vis.sum() - 2
+    np.testing.assert_allclose(a["conic_opacity"][same], b["conic_opacity"][same], rtol=2e-5,
+                               atol=2e-5 * float(np.abs(a["conic_opacity"][same]).max()))
+    if (a["radii"] == b["radii"]).all():
+        np.testing.assert_allclose(a["color"], b["color"], rtol=0, atol=2e-4)
+    # backward: dL_dcov3D -> dL_dscales, dL_drotations.  The fixture's Jacobians are those of the unscaled shapes:
+    # d cov / d scale is linear in the scale (x 1/4), d cov / d rot quadratic (x 1/16)
+    d_cov = a["grads"]["dL_dcov3D"].reshape(P, 6).astype(np.float64)
+    want_ds = np.einsum("pjk,pk->pj", jac_s.astype(np.float64) * 0.25, d_cov)
+    want_dr = np.einsum("pjk,pk->pj", jac_r.astype(np.float64) / 16.0, d_cov)
+    got_ds = a["grads"]["dL_dscales"].reshape(P, 3)
+    got_dr = tangential(z["rotations"].astype(np.float64), a["grads"]["dL_drotations"].reshape(P, 4).astype(np.float64))
+    assert float(np.abs(want_ds[vis]).max()) > 1e-3 and float(np.abs(want_dr[vis]).max()) > 1e-3
+    np.testing.assert_allclose(got_ds[vis], want_ds[vis], rtol=0, atol=4e-6 * float(np.abs(want_ds[vis]).max()))
+    np.testing.assert_allclose(got_dr[vis], want_dr[vis], rtol=0, atol=4e-6 * float(np.abs(want_dr[vis]).max()))
+    # per Gaussian too, so that the largest splat does not hide the others
+    # (a row's error is measured against the sum of the magnitudes of the terms that form it)
+    for got, want, jac in ((got_ds, want_ds, jac_s * 0.25), (got_dr, want_dr, jac_r / 16.0)):
+        terms = np.einsum("pjk,pk->pj", np.abs(jac.astype(np.float64)), np.abs(d_cov)) + 1e-30
+        assert float((np.abs(got[vis] - want[vis]) / terms[vis]).max()) < 2e-5
+    assert not a["grads"]["dL_dscales"].reshape(P, 3)[~vis].any()
 
 
 def test_empty_scene(dgr):
