@@ -248,7 +248,8 @@ def main():
         L = _C.lib()
         L.ngs_debug_depth_order_taken.restype = ctypes.c_int
         taken = int(L.ngs_debug_depth_order_taken())
-        depth_order = {"taken": {0: "per-tile sort of the instances", 1: "sort of the Gaussians first"}.get(taken)}
+        depth_order = {"taken": {0: "per-tile sort of the instances", 1: "sort of the Gaussians first"}.get(taken),
+                       "how": "by the cost of either on this process's earlier frames, clocked on the device"}
         for choice, key in ((0, "ms_per_step_per_tile_sort"), (1, "ms_per_step_gaussians_first")):
             L.ngs_debug_depth_order(choice)
             n = max(min(args.steps, 20), 1)
@@ -265,6 +266,12 @@ def main():
         for _ in range(2):  # the capacity estimate and the caches back to the automatic choice
             step()
         torch.cuda.synchronize(dev)
+        # what the choice went by: the binning stages as the device clocked them on the last frame with either source
+        ua, ub = ctypes.c_double(), ctypes.c_double()
+        L.ngs_debug_stage_clock.restype = ctypes.c_int
+        if L.ngs_debug_stage_clock(ctypes.byref(ua), ctypes.byref(ub)) == 0:
+            depth_order["device_clocked_binning_us"] = {"per_tile_sort": round(ua.value, 1),
+                                                        "gaussians_first": round(ub.value, 1)}
     stages = {}
     if not args.no_stage_timing:
         stage_steps = min(args.steps, 30) if args.stage_steps is None else args.stage_steps

@@ -418,6 +418,16 @@ int ngs_profile_read(double* total_ms, long long* launches, int reset);
  */
 void ngs_debug_depth_order(int choice);
 int ngs_debug_depth_order_taken(void);
+/*
+ * What the default choice goes by: the device clocks the stages between the scan and the compositing kernel on every
+ * frame, and the library keeps, per calling thread and device and for the current (width, height, P), the last three
+ * such durations with either source of the depth order; once both have three, the one with the cheaper best frame
+ * (per instance) is taken and the other tried again every 128 frames (every 1024 when it was more than a quarter behind).  Returns those two durations in
+ * microseconds as of the last forward call of the calling thread on the current device (-1: not measured yet);
+ * a frame's figure is known to the host only once a later forward call has looked at it.  Return value 1: the platform
+ * has no coherent host memory for the device to post into, the choice is by a fixed cost model.
+ */
+int ngs_debug_stage_clock(double* us_per_tile_sort, double* us_gaussians_first);
 
 /* Message of the last failure on the calling thread ("" if none). */
 const char* ngs_last_error(void);

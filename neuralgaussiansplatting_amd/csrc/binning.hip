@@ -167,6 +167,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int n, co
         }
         misc[0] = total;
         misc[1] = flags;  // written, not merged: nobody has to clear the word before a frame
+        misc[NGS_MISC_T_SCAN] = (uint32_t)wall_clock64();  // the binning stages start here (see render_fwd_kernel)
         // The host is spinning on this word of pinned host memory (it holds ~0 until now): the instance count and
         // the error flag reach it without a copy engine or an interrupt in between.
         if (mailbox)

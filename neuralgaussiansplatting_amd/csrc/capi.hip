@@ -2,6 +2,7 @@
 // include/ngs_rasterizer.h): carve the caller's scratch buffers, run the stages
 // in order on the caller's stream, report errors by return code.  Pipeline
 // order follows cuda_rasterizer/rasterizer_impl.cu:198-434 of the reference.
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -161,10 +162,25 @@ static NgsCamera make_camera(int W, int H, float tanx, float tany, const float* 
 // leaves its 64 bytes behind: freeing from a thread-exit hook could run after the HIP runtime has shut down);
 // NGS_NO_MAILBOX=1 disables it.
 #define NGS_MAX_DEVICES 64
+// What the binning stages (everything between the scan and the compositing kernel) cost on recent frames with either
+// source of the depth order, as the device itself clocked it (render_fwd_kernel posts the figure into word 1 of the
+// mailbox).  Kept per calling thread and device, for one (image size, Gaussian count) at a time.
+#define NGS_ROUTE_PENDING 8
+struct RouteHistory {
+    int W, H, P;
+    uint32_t seq;  // frames launched with a stage clock so far
+    struct { uint32_t seq; int route; double instances; bool valid; } pending[NGS_ROUTE_PENDING];
+    double us[2], instances[2];  // last measurement per route (instances == 0: none yet) and the frame's instance count
+    double per_instance[2][3];   // the last three measurements per route, in us per instance
+    int measured[2];             // how many there have been (the first frames of a process run slow: one is not enough)
+    int age[2];                  // decisions since route r was last taken
+    double ticks_per_us;
+};
 struct Mailbox {
-    unsigned long long* host;
+    unsigned long long* host;  // word 0: instance count and error flags of the frame in flight; word 1: stage clock
     unsigned long long* dev;
     int state;  // 0 = not tried, 1 = ready, -1 = unavailable
+    RouteHistory route;
 };
 
 static Mailbox* mailbox_get()
@@ -190,6 +206,14 @@ static Mailbox* mailbox_get()
                 mb.host = (unsigned long long*)h;
                 mb.dev = (unsigned long long*)d;
                 mb.state = 1;
+                memset(&mb.route, 0, sizeof mb.route);
+                __atomic_store_n(mb.host + 1, 0ull, __ATOMIC_RELEASE);
+                int khz = 0;  // rate of the constant clock wall_clock64() reads
+                if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) {
+                    (void)hipGetLastError();
+                    khz = 100000;
+                }
+                mb.route.ticks_per_us = khz * 1e-3;
             } else {
                 (void)hipGetLastError();
             }
@@ -229,6 +253,14 @@ static bool mailbox_wait(Mailbox* mb, hipStream_t st, uint32_t out[2])
 }
 
 extern "C" const char* ngs_last_error(void) { return g_err; }
+
+extern "C" int ngs_debug_stage_clock(double* us_per_tile_sort, double* us_gaussians_first)
+{
+    Mailbox* mb = mailbox_get();
+    if (us_per_tile_sort) *us_per_tile_sort = mb && mb->route.instances[0] > 0.0 ? mb->route.us[0] : -1.0;
+    if (us_gaussians_first) *us_gaussians_first = mb && mb->route.instances[1] > 0.0 ? mb->route.us[1] : -1.0;
+    return mb ? 0 : 1;
+}
 
 extern "C" size_t ngs_required_geometry_bytes(int P) { return ngs_geom_layout((size_t)(P > 0 ? P : 0)).total; }
 extern "C" size_t ngs_required_binning_bytes(long long R) { return ngs_bin_layout((size_t)(R > 0 ? R : 0)).total; }
@@ -319,12 +351,57 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     // (0.085 ms at 1500 per tile on average and 12 M instances), rising steeply where the longest lists do (2900 per
     // tile on average and 24 M instances).
     const int T = cam.grid_x * cam.grid_y;
+    // That model only opens the bidding.  How long a tile's list takes to sort depends on how the scene loads the
+    // tiles and how its depths crowd, which the host cannot know -- so the device clocks the binning stages of
+    // every frame (RouteHistory) and the choice goes by what each source has actually cost on this thread's recent
+    // frames of the same size, scaled by the instance count; the one not in use is tried again now and then (rarely
+    // when it was far behind).  Both give the same lists, so the choice never shows in the results.
+    Mailbox* mb = mailbox_get();
+    RouteHistory* rh = mb ? &mb->route : nullptr;
+    if (rh) {
+        if (rh->W != width || rh->H != height || rh->P != P) {
+            const double rate = rh->ticks_per_us;
+            const uint32_t seq = rh->seq;
+            memset(rh, 0, sizeof *rh);
+            rh->ticks_per_us = rate;
+            rh->seq = seq;
+            rh->W = width; rh->H = height; rh->P = P;
+        }
+        const unsigned long long word = __atomic_load_n(mb->host + 1, __ATOMIC_ACQUIRE);
+        const uint32_t seq = (uint32_t)(word >> 32);
+        auto& pend = rh->pending[seq % NGS_ROUTE_PENDING];
+        if (pend.valid && pend.seq == seq && pend.instances > 0.0) {
+            const int r = pend.route;
+            rh->us[r] = (double)(uint32_t)word / rh->ticks_per_us;
+            rh->instances[r] = pend.instances;
+            rh->per_instance[r][rh->measured[r]++ % 3] = rh->us[r] / pend.instances;
+            pend.valid = false;
+        }
+    }
     auto sort_gaussians_first = [&](int64_t instances) {
         if (g_depth_order_choice >= 0) return g_depth_order_choice == 1;
         const double inst = (double)instances, per_tile = inst / (double)T;
-        const double by_tile = 12.0 + 6.1e-6 * inst * (per_tile > 2600.0 ? 1.0 + (per_tile - 2600.0) / 150.0 : 1.0);
-        const double by_gaussian = 50.0 + 45e-6 * (double)P;
-        return by_gaussian < by_tile;
+        const double model[2] = {12.0 + 6.1e-6 * inst * (per_tile > 2600.0 ? 1.0 + (per_tile - 2600.0) / 150.0 : 1.0),
+                                 50.0 + 45e-6 * (double)P};
+        const int by_model = model[1] < model[0] ? 1 : 0;
+        if (!rh || inst <= 0.0) return by_model == 1;
+        int pick;
+        if (rh->measured[0] == 0 && rh->measured[1] == 0) {
+            pick = by_model;
+        } else if (rh->measured[0] < 3 || rh->measured[1] < 3) {
+            // three frames with either before the figures count (a frame's figure reaches the host a call later, so
+            // a source may get a frame or two more than that)
+            pick = rh->measured[0] == rh->measured[1] ? by_model : rh->measured[1] < rh->measured[0] ? 1 : 0;
+        } else {
+            // the smallest of the last three measurements: a frame that was held up says nothing about its source
+            double est[2];
+            for (int r = 0; r < 2; r++)
+                est[r] = inst * fmin(rh->per_instance[r][0], fmin(rh->per_instance[r][1], rh->per_instance[r][2]));
+            const int best = est[1] < est[0] ? 1 : 0, other = 1 - best;
+            pick = ++rh->age[other] >= (est[other] < 1.25 * est[best] ? 128 : 1024) ? other : best;
+        }
+        rh->age[pick] = 0;
+        return pick == 1;
     };
     int64_t capacity = binning_capacity > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)binning_capacity;
     // With a capacity from the caller the choice is made now, and a frame that takes the per-tile sort does not write
@@ -340,7 +417,6 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     prof_end(ps, ST_PREPROCESS, st);
     NGS_STAGE("preprocess");
     prof_begin(ps, ST_SCAN, st);
-    Mailbox* mb = mailbox_get();
     if (mb) __atomic_store_n(mb->host, ~0ull, __ATOMIC_RELEASE);
     ngs_launch_scan_block_sums(st, nblocks, block_sums, block_offs, (const uint32_t*)(gb + gl.block_depths), misc,
                                mb ? mb->dev : nullptr);
@@ -425,18 +501,32 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         NGS_STAGE("identifyTileRanges");
         if (capacity > 0 && !depth_first) {
             prof_begin(ps, ST_SEGSORT, st);
-            ngs_launch_sort_segments(st, T, ranges, depth, tkeys, vals, (uint32_t*)(ib + il.hard), dr, misc);
+            ngs_launch_sort_segments(st, T, ranges, depth, tkeys, vals, (uint32_t*)(ib + il.hard), dr, misc, (uint2*)hist,
+                                     (uint32_t)(ngs_sort_blocks((size_t)capacity) * 128));
             prof_end(ps, ST_SEGSORT, st);
             NGS_STAGE("sort (depth)");
         }
         prof_begin(ps, ST_RENDER_FWD, st);
+        // (a frame whose stages run twice because the estimate was too small is not a measurement)
+        auto* pend = rh && capacity > 0 ? &rh->pending[++rh->seq % NGS_ROUTE_PENDING] : nullptr;
+        if (pend) {
+            pend->seq = rh->seq;
+            pend->route = depth_first ? 1 : 0;
+            pend->instances = count_known ? (double)host_misc[0] : 0.0;
+            pend->valid = true;
+        }
         ngs_launch_render_fwd(st, cam, ranges, vals[0], rec, background, (float*)(ib + il.final_T),
-                              (uint32_t*)(ib + il.n_contrib), out_color, (float*)(gb + gl.acc), P, misc);
+                              (uint32_t*)(ib + il.n_contrib), out_color, (float*)(gb + gl.acc), P, misc,
+                              pend ? mb->dev + 1 : nullptr, pend ? pend->seq : 0u);
         prof_end(ps, ST_RENDER_FWD, st);
         NGS_STAGE("render");
         if (count_known) break;
         if (learn_count()) return 1;
-        if ((int64_t)host_misc[0] <= capacity) break;
+        if ((int64_t)host_misc[0] <= capacity) {
+            if (pend && pend->seq == rh->seq) pend->instances = (double)host_misc[0];
+            break;
+        }
+        if (pend) pend->valid = false;
         // The estimate was too small: the stages above worked on a truncated list (inside the buffer, so harmlessly).
         // Queue them again with a buffer that holds every instance.
         capacity = (int64_t)host_misc[0];

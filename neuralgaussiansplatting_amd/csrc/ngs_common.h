@@ -22,6 +22,7 @@
 #define NGS_MISC_DMIN 2       // lower bound of the visible Gaussians' depth bits
 #define NGS_MISC_DMAX 3       // upper bound
 #define NGS_MISC_ACC_CLEAN 4  // 1: the gradient accumulator rows are all zero (the forward pass left them so)
+#define NGS_MISC_T_SCAN 5     // low 32 bits of the device's constant-rate clock when the scan kernel finished
 // Slots of one accumulator row filled by the backward compositing kernel, summed over the pixels a Gaussian was
 // blended at (d = Gaussian centre - pixel, G = exp(power), o = opacity): DX, DY = sum of o dL/dalpha G d;
 // CON_A, CON_B, CON_C = sum of o dL/dalpha G (dx^2, dx dy, dy^2); OPAC = sum of dL/dalpha G = dL/dopacity;
@@ -72,7 +73,8 @@ struct ImageLayout {
     size_t final_T;   // float[T*256] tile-major: pixel (tile, ly*16+lx)
     size_t n_contrib; // u32  [T*256] tile-major
     size_t ranges;    // uint2[T]
-    size_t hard;      // u32[4 + 2T]: work lists of the per-tile sort's later launches; [0], [1] = lengths, list k at 4 + kT
+    size_t hard;      // u32[4 + 2T]: work lists of the per-tile sort's later launches; [0], [1] = lengths, list k at 4 + kT;
+                      // [2] = number of sub-lists the split of long lists made
     size_t total;
 };
 
@@ -333,17 +335,22 @@ void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t cap
                                uint32_t* const vals[2], uint32_t* hist, uint32_t* totals, int bits, int first_bit = 0);
 // Per-tile depth sort of vals[0] (lists in index order inside each tile) by the depth of the listed Gaussians;
 // keys[] and vals[1] are scratch for lists that do not fit a workgroup.
-// hard: u32[4 + 2T] with hard[0] == hard[1] == 0 on entry (see ImageLayout).  dr.key_bits != 0: keys[0] and vals[0]
+// hard: u32[4 + 2T] with hard[0] == hard[1] == hard[2] == 0 on entry (see ImageLayout); subs: room for subs_cap
+// (first, end) pairs (the tile-level sort's histogram, idle by then).  dr.key_bits != 0: keys[0] and vals[0]
 // carry every entry's depth rank (the list leaves without it); misc: the geometry buffer's word array (depth extremes
 // in [2], [3]).
 void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
-                              uint32_t* const vals[2], uint32_t* hard, const DepthRank& dr, const uint32_t* misc);
+                              uint32_t* const vals[2], uint32_t* hard, const DepthRank& dr, const uint32_t* misc,
+                              uint2* subs, uint32_t subs_cap);
 // render_fwd.hip
 // acc / P / misc: the compositing kernel also clears the P gradient accumulator rows for the backward pass (it is
 // bound by arithmetic and leaves the memory system idle) and says so in misc[NGS_MISC_ACC_CLEAN].
+// stage_clock (or NULL): a word of host memory that receives (seq << 32) | ticks of the device's constant-rate clock
+// that passed between the end of the scan kernel and the start of this kernel, i.e. the duration of the binning stages.
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,
-                           uint32_t* n_contrib, float* out_color, float* acc, int P, uint32_t* misc);
+                           uint32_t* n_contrib, float* out_color, float* acc, int P, uint32_t* misc,
+                           unsigned long long* stage_clock, uint32_t seq);
 // render_bwd.hip
 // Clears the accumulator rows unless misc[NGS_MISC_ACC_CLEAN] says they are clear already.
 void ngs_launch_zero_acc_unless_clean(hipStream_t s, float* acc, int P, const uint32_t* misc);

@@ -437,6 +437,245 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 5 : 2) void segment_sort_
     }
 }
 
+// Lists the kernel above cannot take, first step: split by depth.  One workgroup streams a tile's list three times
+// (depth extremes; bucket counts; scatter) and leaves it in the spare buffers grouped into SPLIT_NB buckets by
+// (depth key - the list's smallest) >> s, buckets in order of depth, entries inside a bucket in no particular order.
+// Runs of whole buckets then form sub-lists: a sub-list starts at the first bucket that starts inside each block of
+// SPLIT_GROUP entries, so with no bucket above SPLIT_GROUP entries every sub-list is shorter than 2 SPLIT_GROUP = what
+// one workgroup of segment_sort_sub_kernel holds.  Sub-lists are appended to `subs` ((first, end) positions in the
+// frame's list; hard[2] counts them).  Lists with a fuller bucket (many equal or nearly equal depths), with more than
+// SPLIT_MAX entries, or that find `subs` full go to work list `out` for the general kernel; a list whose depths are
+// all equal is in order already.  Inside a tile the incoming list is in ascending order of the Gaussian index (the
+// instances were emitted in index order and the tile-level passes are stable), so "ties in incoming order" is
+// "ties in index order" and the incoming positions need not be kept.
+#define SPLIT_NB 2048
+#define SPLIT_GROUP 2048
+#define SPLIT_MAX_GROUPS 256
+#define SPLIT_MAX (SPLIT_GROUP * SPLIT_MAX_GROUPS)
+template <bool RANKED>
+__global__ __launch_bounds__(ST) void segment_split_kernel(int T, const uint2* __restrict__ ranges,
+                                                           const float* __restrict__ depth,
+                                                           const uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
+                                                           uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
+                                                           const DepthRank dr, const uint32_t* __restrict__ misc,
+                                                           uint32_t* __restrict__ hard, int in, int out,
+                                                           uint2* __restrict__ subs, uint32_t subs_cap)
+{
+    static_assert(SPLIT_NB == 8 * ST, "thread t scans buckets 8t .. 8t+7");
+    const uint32_t idx_mask = RANKED ? dr.idx_mask() : 0xffffffffu;
+    const bool exact = RANKED && dr.shift(misc[NGS_MISC_DMIN], misc[NGS_MISC_DMAX]) == 0;
+    __shared__ uint32_t s_cnt[SPLIT_NB];
+    __shared__ uint32_t s_first[SPLIT_MAX_GROUPS + 1];  // smallest bucket start inside each block of SPLIT_GROUP entries
+    __shared__ uint32_t s_red[3][SWAVES];
+    __shared__ uint32_t s_word[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n_work = hard[in];
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const uint32_t tile = hard[4 + (size_t)in * T + w];
+        const uint2 range = ranges[tile];
+        const uint32_t n = range.y - range.x;
+        const size_t lo = range.x;
+        if (n > SPLIT_MAX) {  // block-uniform, like every branch below that leaves the trip
+            if (tid == 0) hard[4 + (size_t)out * T + atomicAdd(&hard[out], 1u)] = tile;
+            continue;
+        }
+        auto key_of = [&](uint32_t i, uint32_t& index) {
+            const uint32_t word = vals0[lo + i];
+            index = word & idx_mask;
+            return exact ? dr.join(keys0[lo + i], word) : __float_as_uint(depth[index]);
+        };
+        __syncthreads();  // the previous trip is done with the tables
+        uint32_t kmin = ~0u, kmax = 0u;
+        for (uint32_t i = tid; i < n; i += ST) {
+            uint32_t g;
+            const uint32_t k = key_of(i, g);
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+        }
+        if (lane == 0) { s_red[0][wave] = kmin; s_red[1][wave] = kmax; }
+#pragma unroll
+        for (int j = 0; j < SPLIT_NB / ST; j++) s_cnt[j * ST + tid] = 0;
+        for (int j = tid; j <= SPLIT_MAX_GROUPS; j += ST) s_first[j] = ~0u;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < SWAVES; v++) { kmin = min(kmin, s_red[0][v]); kmax = max(kmax, s_red[1][v]); }
+        const uint32_t span = kmax - kmin;
+        if (span == 0u) {  // one depth for the whole list: the incoming order is the answer
+            if (RANKED)
+                for (uint32_t i = tid; i < n; i += ST) vals0[lo + i] &= idx_mask;
+            continue;
+        }
+        const int sh = max(0, 32 - __clz((int)span) - 11);  // span >> sh < SPLIT_NB
+        for (uint32_t i = tid; i < n; i += ST) {
+            uint32_t g;
+            atomicAdd(&s_cnt[(key_of(i, g) - kmin) >> sh], 1u);
+        }
+        __syncthreads();
+        uint32_t c[8], sum = 0, big = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { c[j] = s_cnt[8 * tid + j]; sum += c[j]; big = max(big, c[j]); }
+        const uint32_t incl = wave_incl_scan_u32(sum, lane);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, o, 64));
+        if (lane == 63) s_red[0][wave] = incl;
+        if (lane == 0) s_red[2][wave] = big;
+        __syncthreads();
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int v = 0; v < SWAVES; v++) {
+            if (v < wave) run += s_red[0][v];
+            big = max(big, s_red[2][v]);
+        }
+        // blocks of SPLIT_GROUP entries the list covers: one slot of `subs` each (a block in which no bucket starts --
+        // only the last can be one while no bucket is above SPLIT_GROUP entries -- leaves its slot an empty sub-list)
+        const uint32_t groups = (n - 1u) / SPLIT_GROUP + 1u;
+        if (tid == 0) s_word[0] = big <= SPLIT_GROUP ? atomicAdd(&hard[2], groups) : ~0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            s_cnt[8 * tid + j] = run;  // the bucket's cursor
+            if (c[j]) atomicMin(&s_first[run / SPLIT_GROUP], run);
+            run += c[j];
+        }
+        __syncthreads();
+        const uint32_t base = s_word[0];
+        const bool room = base != ~0u && base + groups <= subs_cap;
+        if (base != ~0u) {
+            for (uint32_t j = tid; j < groups; j += ST) {
+                if (base + j >= subs_cap) break;
+                const uint32_t first = s_first[j];
+                uint32_t end = n;
+                for (uint32_t k = j + 1; k < groups; k++)
+                    if (s_first[k] != ~0u) { end = s_first[k]; break; }
+                subs[base + j] = (!room || first == ~0u) ? make_uint2(0u, 0u)
+                                                         : make_uint2((uint32_t)lo + first, (uint32_t)lo + end);
+            }
+        }
+        if (!room) {
+            if (tid == 0) hard[4 + (size_t)out * T + atomicAdd(&hard[out], 1u)] = tile;
+            continue;
+        }
+        for (uint32_t i = tid; i < n; i += ST) {
+            uint32_t g;
+            const uint32_t k = key_of(i, g);
+            const uint32_t p = atomicAdd(&s_cnt[(k - kmin) >> sh], 1u);
+            keys1[lo + p] = k;
+            vals1[lo + p] = g;
+        }
+    }
+}
+
+// Second step: every sub-list the split left in the spare buffers (keys1: depth keys, vals1: Gaussian indices;
+// at most SUB_CAP entries, unordered inside) is put in (depth key, index) order by one workgroup and written to its
+// place in the list: the distribution step of segment_sort_bucket_kernel with the tie broken by the index.  A
+// sub-list whose keys are all equal is bucketed by the index instead.  Crowded buckets are simply walked (a
+// sub-list of a few thousand entries bounds the cost), so this kernel hands nothing on.
+#define SUB_CAP (2 * SPLIT_GROUP)
+__global__ __launch_bounds__(ST, 3) void segment_sort_sub_kernel(const uint2* __restrict__ subs, uint32_t subs_cap,
+                                                                 const uint32_t* __restrict__ hard,
+                                                                 const uint32_t* __restrict__ keys1,
+                                                                 const uint32_t* __restrict__ vals1,
+                                                                 uint32_t* __restrict__ vals0)
+{
+    constexpr int ITEMS = SUB_CAP / ST, NB = 8 * ST;
+    __shared__ uint32_t s_cnt[NB];
+    __shared__ uint32_t s_key[SUB_CAP];
+    __shared__ uint32_t s_val[SUB_CAP];
+    __shared__ uint32_t s_red[2][SWAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n_work = min(hard[2], subs_cap);
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const uint2 range = subs[w];
+        const int n = (int)(range.y - range.x);
+        const size_t lo = range.x;
+        if (n < 1 || n > SUB_CAP) continue;  // block-uniform (longer ones do not occur: see the split kernel)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NB / ST; j++) s_cnt[j * ST + tid] = 0;
+        uint32_t key[ITEMS], val[ITEMS];
+        uint32_t kmin = ~0u, kmax = 0u, vmin = ~0u, vmax = 0u;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int slot = i * ST + tid;
+            const bool valid = i * ST < n && slot < n;
+            key[i] = valid ? keys1[lo + slot] : 0u;
+            val[i] = valid ? vals1[lo + slot] : 0u;
+            if (valid) {
+                kmin = min(kmin, key[i]); kmax = max(kmax, key[i]);
+                vmin = min(vmin, val[i]); vmax = max(vmax, val[i]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+            vmin = min(vmin, (uint32_t)__shfl_xor((int)vmin, o, 64));
+            vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, o, 64));
+        }
+        if (lane == 0) { s_key[wave] = kmin; s_key[SWAVES + wave] = kmax; s_val[wave] = vmin; s_val[SWAVES + wave] = vmax; }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < SWAVES; v++) {
+            kmin = min(kmin, s_key[v]); kmax = max(kmax, s_key[SWAVES + v]);
+            vmin = min(vmin, s_val[v]); vmax = max(vmax, s_val[SWAVES + v]);
+        }
+        const bool by_index = kmax == kmin;  // one depth: the order is the index order
+        const uint32_t bmin = by_index ? vmin : kmin, span = by_index ? vmax - vmin : kmax - kmin;
+        const int sh = span ? max(0, 32 - __clz((int)span) - 11) : 0;  // span >> sh < NB
+        static_assert(NB == 2048, "11 bits of bucket number");
+        __syncthreads();  // the extremes have been read out of s_key / s_val
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int slot = i * ST + tid;
+            if (i * ST < n && slot < n) atomicAdd(&s_cnt[((by_index ? val[i] : key[i]) - bmin) >> sh], 1u);
+        }
+        __syncthreads();
+        {
+            uint32_t c[8], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { c[j] = s_cnt[8 * tid + j]; sum += c[j]; }
+            const uint32_t incl = wave_incl_scan_u32(sum, lane);
+            if (lane == 63) s_red[0][wave] = incl;
+            __syncthreads();
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int v = 0; v < SWAVES; v++)
+                if (v < wave) run += s_red[0][v];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { s_cnt[8 * tid + j] = run; run += c[j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int slot = i * ST + tid;
+            if (i * ST < n && slot < n) {
+                const uint32_t p = atomicAdd(&s_cnt[((by_index ? val[i] : key[i]) - bmin) >> sh], 1u);
+                s_key[p] = key[i];
+                s_val[p] = val[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int slot = i * ST + tid;
+            if (i * ST < n && slot < n) {
+                const uint32_t b = ((by_index ? val[i] : key[i]) - bmin) >> sh;
+                const uint32_t begin = b ? s_cnt[b - 1] : 0u, end = s_cnt[b];
+                uint32_t r = begin;
+                for (uint32_t e = begin; e < end; e++) {
+                    const uint32_t k = s_key[e];
+                    r += (k < key[i] || (k == key[i] && s_val[e] < val[i])) ? 1u : 0u;
+                }
+                vals0[lo + r] = val[i];
+            }
+        }
+    }
+}
+
 // The general per-tile sort: four stable 8-bit passes over the depth bits, chunk by chunk, ping-ponging through the
 // spare buffers (depth bits in keys0 / keys1, the list in vals0 / vals1; four passes end where they started, in
 // vals0).  Any list length, any distribution of depths; workgroups share out the tiles of work list `in`.
@@ -564,14 +803,25 @@ void ngs_launch_sort_tile_bits(hipStream_t s, const uint32_t* count, int64_t cap
 // once lists outgrow a workgroup), the Gaussian-level sort's with the number of Gaussians: the forward pass picks
 // whichever is cheaper for the call.
 void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const float* depth, uint32_t* const keys[2],
-                              uint32_t* const vals[2], uint32_t* hard, const DepthRank& dr, const uint32_t* misc)
+                              uint32_t* const vals[2], uint32_t* hard, const DepthRank& dr, const uint32_t* misc,
+                              uint2* subs, uint32_t subs_cap)
 {
+    // work list 0: what the first kernel hands on; work list 1: what the split hands on
     if (dr.key_bits > 0)
         hipLaunchKernelGGL((segment_sort_bucket_kernel<ST, true>), dim3(T), dim3(ST), 0, s, T, ranges, depth, keys[0],
                            dr, misc, vals[0], hard, -1, 0);
     else
         hipLaunchKernelGGL((segment_sort_bucket_kernel<ST, false>), dim3(T), dim3(ST), 0, s, T, ranges, depth, keys[0],
                            dr, misc, vals[0], hard, -1, 0);
+    const int split_grid = T < 2048 ? T : 2048;
+    if (dr.key_bits > 0)
+        hipLaunchKernelGGL(segment_split_kernel<true>, dim3(split_grid), dim3(ST), 0, s, T, ranges, depth, keys[0],
+                           vals[0], keys[1], vals[1], dr, misc, hard, 0, 1, subs, subs_cap);
+    else
+        hipLaunchKernelGGL(segment_split_kernel<false>, dim3(split_grid), dim3(ST), 0, s, T, ranges, depth, keys[0],
+                           vals[0], keys[1], vals[1], dr, misc, hard, 0, 1, subs, subs_cap);
+    hipLaunchKernelGGL(segment_sort_sub_kernel, dim3(2048), dim3(ST), 0, s, subs, subs_cap, hard, keys[1], vals[1],
+                       vals[0]);
     hipLaunchKernelGGL(segment_sort_long_kernel, dim3(T < 512 ? T : 512), dim3(ST), 0, s, T, ranges, depth, keys[0],
-                       vals[0], keys[1], vals[1], hard, 0, dr.key_bits > 0 ? dr.idx_mask() : 0xffffffffu);
+                       vals[0], keys[1], vals[1], hard, 1, dr.key_bits > 0 ? dr.idx_mask() : 0xffffffffu);
 }

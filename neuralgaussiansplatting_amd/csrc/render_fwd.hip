@@ -21,7 +21,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
     const float4* __restrict__ rec_g, const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ acc, int acc_f4_per_block, int acc_f4_total,
-    uint32_t* __restrict__ misc)
+    uint32_t* __restrict__ misc, unsigned long long* __restrict__ stage_clock, uint32_t seq)
 {
     // per wave, record k: [0] = {x, y, -, -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, -}; 64-byte slots, so
     // the address of slot k is a shift-and-add (a 48-byte stride costs a quarter-rate 64-bit multiply-add per visit)
@@ -33,7 +33,15 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
     {
         const int lo = tile * acc_f4_per_block, hi = min(acc_f4_total, lo + acc_f4_per_block);
         for (int i = lo + tid; i < hi; i += NGS_TILE_PIX) stream_store4(acc + 4 * (size_t)i, make_float4(0.f, 0.f, 0.f, 0.f));
-        if (tile == 0 && tid == 0) misc[NGS_MISC_ACC_CLEAN] = 1u;
+        if (tile == 0 && tid == 0) {
+            misc[NGS_MISC_ACC_CLEAN] = 1u;
+            // How long the binning stages between the scan and this kernel took, posted to the host, which picks
+            // the source of the depth order for later frames by what each one has cost (capi.hip).
+            if (stage_clock)
+                __hip_atomic_store(stage_clock, ((unsigned long long)seq << 32) |
+                                                    (uint32_t)((uint32_t)wall_clock64() - misc[NGS_MISC_T_SCAN]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int px = tx * NGS_TILE_W + tile_local_x(tid), py = ty * NGS_TILE_H + tile_local_y(tid);
@@ -139,10 +147,11 @@ __global__ __launch_bounds__(NGS_TILE_PIX) void render_fwd_kernel(
 
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,
-                           uint32_t* n_contrib, float* out_color, float* acc, int P, uint32_t* misc)
+                           uint32_t* n_contrib, float* out_color, float* acc, int P, uint32_t* misc,
+                           unsigned long long* stage_clock, uint32_t seq)
 {
     const int T = cam.grid_x * cam.grid_y;
     const long long f4 = (long long)P * (NGS_ACC_STRIDE / 4);  // P <= NGS_MAX_GAUSSIANS keeps this inside an int
     hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(NGS_TILE_PIX), 0, s, cam.W, cam.H, cam.grid_x, ranges, plist,
-                       rec, bg, final_T, n_contrib, out_color, acc, (int)((f4 + T - 1) / T), (int)f4, misc);
+                       rec, bg, final_T, n_contrib, out_color, acc, (int)((f4 + T - 1) / T), (int)f4, misc, stage_clock, seq);
 }

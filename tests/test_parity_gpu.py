@@ -431,11 +431,19 @@ def test_debug_mode_same_result(dgr, oracle):
 MAX_KNIFE_EDGE = {"c2": 4, "c3": 4, "c4": 12, "c5": 12, "c4s": 12, "c4s_small": 4}
 
 
-# Scenes with splats hundreds of pixels wide: a Gaussian's gradient is a float32 sum of up to a million per-pixel terms,
-# and the checker's sum in the reference's order (one term after the other) is itself up to 1.2e-5 of the tensor's
-# largest element away from the exact sum of the same terms.  There the library is held to the tight bar against the
-# checker's sums kept in double precision, and to this one against the reference-order float32 sums.
-HEAVY_TAIL_REFERENCE_ORDER_BAR = 3e-5
+# Scenes with splats hundreds of pixels wide: a Gaussian's gradient is a float32 sum of up to a million per-pixel terms
+# that cancel heavily, and the chain from the conic's gradient to scale and rotation amplifies what the sum's rounding
+# leaves.  The checker's sum in the reference's order (one term after the other, one thread) is itself up to 1.2e-5
+# of the tensor's largest element away from the exact sum of the same terms.  There the library is held to
+# the tight bar in the backward pass's two stages -- the compositing stage's sums against the checker's sums kept in
+# double precision, then the per-Gaussian chain with the checker fed the library's own sums -- and end to end to
+# HEAVY_TAIL_BAR against the double-precision sums (observed: 3e-6 at 200 k Gaussians, 1.2e-5 at 3 M; the order of
+# the float atomics differs from run to run).  Against the reference-order float32 sums the deviation is the
+# checker's own summation error (at c4s' full size 3e-5 of dL_dscales' largest element): there only the absolute
+# bar for the loss normalised by the pixel count is asserted, plus a coarse relative one, and the table records how
+# far the two checkers are from each other.
+HEAVY_TAIL_BAR = 4e-5
+HEAVY_TAIL_REFERENCE_ORDER_BAR = 2e-4
 
 
 def full_size_parity(dgr, oracle, cfg, view=0, views=None, dL_seed=5, label=None, threads=8, heavy_tailed=False):
@@ -453,16 +461,34 @@ def full_size_parity(dgr, oracle, cfg, view=0, views=None, dL_seed=5, label=None
         o = oracle_forward(oracle, c)
         h = run_hip(dgr, c, dL_dpix=dL)
         edge = check_forward(o, h, exact_pixels=False, max_knife_edge=MAX_KNIFE_EDGE[cfg])
-        og = oracle_backward(oracle, c, o, dL)
+        og = None if heavy_tailed else oracle_backward(oracle, c, o, dL)
         if heavy_tailed:
-            worst32 = check_grads_full_size(h["grads"], og, o, edge, W, H, bar=HEAVY_TAIL_REFERENCE_ORDER_BAR)
+            hg = h["grads"]
+            # the compositing stage's sums against the same float32 terms summed in double precision
             ogw = oracle_backward(oracle, c, o, dL, wide_sums=True)
-            worst = check_grads_full_size(h["grads"], ogw, o, edge, W, H)
-            k32 = max(worst32, key=worst32.get)
-            record_pixel_errors((label or cfg) + " vs the checker's sums in double precision", W, H, h["R"], edge,
-                                worst, MAX_KNIFE_EDGE[cfg])
-            record_pixel_errors((label or cfg) + " vs the checker's float32 sums in the reference's order", W, H,
-                                h["R"], edge, {k32: worst32[k32]}, MAX_KNIFE_EDGE[cfg])
+            stage1 = check_grads_full_size({k: hg[k] for k in STAGE1}, {k: ogw[k] for k in STAGE1}, o, edge, W, H)
+            # the per-Gaussian chain on identical inputs (the library's own sums)
+            og2 = oracle_backward(oracle, c, o, dL, stage1={k: hg[k] for k in STAGE1})
+            chain = {}
+            for name, ref in og2.items():
+                if name not in STAGE1:
+                    big = float(np.abs(ref).max())
+                    chain[name] = float(np.abs(hg[name].reshape(ref.shape) - ref).max()) / big
+                    assert chain[name] <= FULL_SIZE_GRAD_REL_TO_MAX, "%s (same stage-1 sums): %.2e of its largest element" % (
+                        name, chain[name])
+            # end to end against the double-precision sums, and against the reference's order
+            worst = check_grads_full_size(hg, ogw, o, edge, W, H, bar=HEAVY_TAIL_BAR)
+            oracle.set_threads(1)  # the reference's order: one term after the other
+            og = oracle_backward(oracle, c, o, dL)
+            worst32 = check_grads_full_size(hg, og, o, edge, W, H, bar=HEAVY_TAIL_REFERENCE_ORDER_BAR)
+            between = {k: float(np.abs(og[k] - ogw[k]).max()) / float(np.abs(ogw[k]).max()) for k in og}
+            for tag, table in ((": compositing sums vs the checker's sums in double precision", stage1),
+                               (": per-Gaussian chain, checker fed the library's sums", chain),
+                               (": end to end vs the checker's sums in double precision", worst),
+                               (": end to end vs the checker's float32 sums in the reference's order", worst32),
+                               (": the checker's float32 reference-order sums vs its double-precision sums", between)):
+                k = max(table, key=table.get)
+                record_pixel_errors((label or cfg) + tag, W, H, h["R"], edge, {k: table[k]}, MAX_KNIFE_EDGE[cfg])
         else:
             worst = check_grads_full_size(h["grads"], og, o, edge, W, H)
             record_pixel_errors(label or cfg, W, H, h["R"], edge, worst, MAX_KNIFE_EDGE[cfg])
@@ -537,6 +563,38 @@ def test_trained_scene_like_3m_1080p_full_size(dgr, oracle):
     per_tile = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
     assert h["R"] == o["num_rendered"] > 12_000_000 and per_tile.max() > 20_000
     assert int(h["tiles_touched"].sum()) == h["R"]
+
+
+def test_depth_order_is_chosen_by_what_each_source_has_cost(dgr, oracle):
+    """Left alone, the forward pass clocks its binning stages on the device and, after both sources of the depth
+    order have been tried on frames of one size, keeps to the cheaper one: on a scene whose tiles hold tens of
+    thousands of instances that is the sort of the Gaussians, on a uniform cloud of small splats the per-tile sort;
+    the image is the same bit for bit whichever ran."""
+    import ctypes
+    L = dgr._lib.lib()
+    L.ngs_debug_depth_order_taken.restype = ctypes.c_int
+    L.ngs_debug_stage_clock.restype = ctypes.c_int
+    from neuralgaussiansplatting_amd import synthetic
+    L.ngs_debug_depth_order(-1)
+    for cfg in ("c4s_small", "c2"):
+        sc, W, H = synthetic.make_config(cfg, seed=1234)
+        cam = synthetic.make_view(W, H, 0)
+        c = dict(scene=sc, cam=cam, W=W, H=H, D=sc.sh_degree, bg=torch.zeros(3), tanfovx=math.tan(cam.FoVx * 0.5),
+                 tanfovy=math.tan(cam.FoVy * 0.5))
+        taken, first = [], None
+        for frame in range(10):
+            h = run_hip(dgr, c)
+            taken.append(int(L.ngs_debug_depth_order_taken()))
+            if first is None:
+                first = h
+            assert np.array_equal(h["color"], first["color"]) and np.array_equal(h["point_list"], first["point_list"])
+        a, b = ctypes.c_double(), ctypes.c_double()
+        assert L.ngs_debug_stage_clock(ctypes.byref(a), ctypes.byref(b)) == 0
+        assert set(taken) == {0, 1}, "both sources were tried: %r" % taken
+        assert a.value > 0.0 and b.value > 0.0, (a.value, b.value)
+        cheaper = 0 if a.value <= b.value else 1
+        if min(a.value, b.value) < 0.8 * max(a.value, b.value):  # a clear difference: the last frames keep to it
+            assert taken[-3:] == [cheaper] * 3, (cfg, taken, a.value, b.value)
 
 
 def test_closed_form_three_gaussian_scene(dgr):
