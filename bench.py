@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--exchange", default="factored", choices=("factored", "dense"),
                     help="gradient exchange at N > 1: all-gather of masked colour gradients + all-reduce of the other "
                          "11 floats per Gaussian (default), or one dense all-reduce of all 59")
+    ap.add_argument("--chunks", type=int, default=None,
+                    help="runs of Gaussians the per-Gaussian stage of the backward pass is queued in at N > 1, each "
+                         "run's gradients leaving in a collective of their own while the next is computed (default 4)")
     ap.add_argument("--views-per-gpu", type=int, default=1,
                     help="views each GPU renders per step (the step's gradient is the sum over all GPUs' views): with "
                          "more than one, a view's collectives travel while the next view is rendered and only the "
@@ -182,17 +185,20 @@ def main():
     bg = torch.zeros(3, device=dev)
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     dL = (torch.randn(3, H, W, generator=gen) / float(W * H)).to(dev)
-    if (world > 1 or V > 1) and args.exchange == "factored":
-        bucket = view_parallel.FactoredGradientExchange(P, M, dev, views_per_rank=V)
-    else:
-        bucket = view_parallel.GradientBucket(P, M, dev, views_per_rank=V)
+    def make_exchange(form, chunks=None):
+        if (world > 1 or V > 1) and form == "factored":
+            return view_parallel.FactoredGradientExchange(P, M, dev, views_per_rank=V, chunks=chunks)
+        return view_parallel.GradientBucket(P, M, dev, views_per_rank=V, chunks=chunks)
+
+    bucket = make_exchange(args.exchange, args.chunks)
     exchanged_floats = bucket.bytes_sent_per_rank() // 4
 
-    def step():
+    def step(b=None):
+        b = bucket if b is None else b
         for k in range(V):
-            out = view_parallel.forward_backward(scene, cams[k], bg, lambda color: dL, bucket, tanx, tany, slot=k)
-            bucket.post_view(k, scene, cams[k], out[2])
-        bucket.finish(scene)
+            out = view_parallel.forward_backward(scene, cams[k], bg, lambda color: dL, b, tanx, tany, slot=k)
+            b.post_view(k, scene, cams[k], out[2])
+        b.finish(scene)
         return out
 
     def fence():
@@ -284,6 +290,47 @@ def main():
         stages = _C.profile_read(reset=True)
         _C.profile_enable(False)
         note("stage timing done")
+
+    # ---- the exchange on its own clock, and the other form of it, so that one run records both ----
+    exchange = None
+    if world > 1:
+        def clocked(b, n):
+            for _ in range(2):
+                step(b)
+            b.enable_clock(True)
+            with quiet_host():
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    step(b)
+                fence()
+                t = time.perf_counter() - t0
+            total, exposed = b.clock_read() if args.backend == "nccl" else (None, None)
+            b.enable_clock(False)
+            vals = torch.tensor([t, -1.0 if total is None else total, -1.0 if exposed is None else exposed],
+                                dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+            t, total, exposed = (float(v) for v in vals.tolist())
+            r4 = lambda v: None if v < 0 else round(v, 4)
+            return {"ms_per_step": round(t / n * 1e3, 4), "exchange_ms_total": r4(total),
+                    "exchange_ms_exposed": r4(exposed), "runs_of_gaussians": b.K,
+                    "floats_per_rank_and_step": b.bytes_sent_per_rank() // 4}
+
+        n_ex = max(min(args.steps, 20), 1)
+        exchange = {"headline": dict(clocked(bucket, n_ex), form=args.exchange),
+                    "what": "exchange_ms_total: from the moment the step's first collective is handed its data until "
+                            "the last one has been waited for; exchange_ms_exposed: the part of that after this "
+                            "rank's own kernels of the step have run (HIP events on the compute stream, slowest rank, "
+                            "%d steps)" % n_ex}
+        other_form = "dense" if args.exchange == "factored" else "factored"
+        variants = [(other_form, args.chunks)]
+        if bucket.K > 1:
+            variants.append((args.exchange, 1))  # the headline form sent in one piece
+        for form, chunks in variants:
+            b2 = make_exchange(form, chunks)
+            exchange["%s%s" % (form, "" if chunks is None else "_unchunked")] = dict(clocked(b2, n_ex), form=form)
+            del b2
+        note("exchange variants done")
 
     # ---- second loop: whole training iterations ----
     # The training loop fits a random target, which changes the scene (opacities fall, every pixel composites more
@@ -472,15 +519,18 @@ def main():
                         "ms_per_step_min": round(min(loops) / args.steps * 1e3, 4),
                         "ms_per_step_median": round(elapsed / args.steps * 1e3, 4),
                         "ms_per_step_max": round(max(loops) / args.steps * 1e3, 4)},
-            "depth_order": depth_order,
+            "depth_order": depth_order, "exchange": exchange,
             "config": {"workload": "%s%s: %d Gaussians, %dx%d, SH degree %d (M=%d), %s per GPU and step, "
                                    "fwd+bwd%s" % (args.config,
                                                   "" if args.log_scale_offset == 0.0 else
                                                   " with log-scale offset %+.2f" % args.log_scale_offset,
                                                   P, W, H, D, M,
                                                   "one orbit view" if V == 1 else "%d orbit views" % V,
-                                                  " + %s gradient exchange of %d floats per rank and step"
-                                                  % (args.exchange, exchanged_floats) if world > 1 else ""),
+                                                  " + %s gradient exchange of %d floats per rank and step in %d "
+                                                  "collective(s) per view"
+                                                  % (args.exchange, exchanged_floats,
+                                                     bucket.K + (1 if args.exchange == "factored" else 0))
+                                                  if world > 1 else ""),
                        "views_per_gpu": V,
                        "gaussians": P, "width": W, "height": H, "sh_degree": D, "instances_R": int(R),
                        "instances_per_gaussian": round(R / P, 2), "log_scale": [round(v, 3) for v in ls],

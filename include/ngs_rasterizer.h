@@ -226,6 +226,38 @@ int ngs_rasterize_backward_early_color(int P, int D, int M, int R, const float* 
                                        float* dL_dscale, float* dL_drot, int debug, void* stream, float* masked_color,
                                        void (*color_ready)(void*), void* color_ready_ctx);
 
+/*
+ * ngs_rasterize_backward_early_color with the per-Gaussian stage queued in n_chunks pieces, so that a collective on
+ * the gradients of the Gaussians of chunk k can start while the later chunks are still being computed.  No
+ * counterpart in the reference (single GPU).  chunks[k] covers Gaussians [first, first + count); the chunks tile
+ * [0, P) in order and every `first` is a multiple of 256.  The five gradients a multi-GPU caller exchanges may be
+ * redirected per chunk: a non-NULL pointer receives the chunk's rows of that array (row 0 = Gaussian `first`; dL_drot
+ * and dL_dsh 16-byte aligned) instead of rows [first, first + count) of the whole array, which may then be NULL if
+ * every chunk redirects it.  All other outputs go to the whole arrays as in ngs_rasterize_backward.  chunk_ready (may
+ * be NULL) is called on the host with (chunk_ready_ctx, k) right after chunk k's kernel has been queued on `stream`:
+ * an event recorded there completes when the chunk's gradients are final.  masked_color may be NULL (then there is
+ * no hand-over and color_ready is not called).  Results are those of the unchunked call, bit for bit.
+ */
+typedef struct ngs_gradient_chunk {
+    int first, count;
+    float* dL_dmean3D; /* [count][3] or NULL */
+    float* dL_dopacity; /* [count] */
+    float* dL_dscale; /* [count][3] */
+    float* dL_drot; /* [count][4] */
+    float* dL_dsh; /* [count][M][3] */
+} ngs_gradient_chunk;
+int ngs_rasterize_backward_chunked(int P, int D, int M, int R, const float* background, int width, int height,
+                                   const float* means3D, const float* shs, const float* colors_precomp,
+                                   const float* scales, float scale_modifier, const float* rotations,
+                                   const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                   const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                                   char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                                   float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                                   float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                                   int debug, void* stream, float* masked_color, void (*color_ready)(void*),
+                                   void* color_ready_ctx, int n_chunks, const ngs_gradient_chunk* chunks,
+                                   void (*chunk_ready)(void*, int), void* chunk_ready_ctx);
+
 /* Rasterizer::markVisible (rasterizer.h:24-29, rasterizer_impl.cu:141-153):
  * present[i] = 1 if Gaussian i passes the near-plane test, else 0 (bytes). */
 int ngs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

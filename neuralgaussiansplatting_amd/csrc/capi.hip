@@ -591,6 +591,14 @@ struct EarlyColor {
     void* ctx;
 };
 
+// The per-Gaussian stage in pieces (ngs_rasterize_backward_chunked)
+struct ChunkPlan {
+    int n;
+    const ngs_gradient_chunk* chunks;
+    void (*ready)(void*, int);
+    void* ctx;
+};
+
 static int backward_impl(const char* fn, int P, int D, int M, int R, const float* background, int width, int height,
                          const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                          float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -600,7 +608,7 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
                          float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                          float* dL_drot, int debug, void* stream, const ShAdamArgs* sh_adam,
                          const EarlyColor* early = nullptr, const float* opacities_raw = nullptr,
-                         const GeoAdamArgs* geo = nullptr)
+                         const GeoAdamArgs* geo = nullptr, const ChunkPlan* plan = nullptr)
 {
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
@@ -650,10 +658,34 @@ static int backward_impl(const char* fn, int P, int D, int M, int R, const float
     prof_begin(ps, ST_PREPROCESS_BWD, st);
     // scales == NULL (precomputed covariance) skips the scale/rotation gradients, shs == NULL the SH ones,
     // as in the reference (backward.cu:390-395).
-    ngs_launch_preprocess_bwd(st, P, D, M, means3D, radii, shs, (const uint8_t*)(gb + gl.clamped),
-                              cov3D_precomp ? nullptr : scales, rotations, opacities_raw, scale_modifier,
-                              cov3D_precomp, cam, acc, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
-                              dL_dcov3D, dL_dsh, dL_dscale, dL_drot, sh_adam, geo);
+    if (!plan) {
+        ngs_launch_preprocess_bwd(st, P, D, M, means3D, radii, shs, (const uint8_t*)(gb + gl.clamped),
+                                  cov3D_precomp ? nullptr : scales, rotations, opacities_raw, scale_modifier,
+                                  cov3D_precomp, cam, acc, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
+                                  dL_dcov3D, dL_dsh, dL_dscale, dL_drot, sh_adam, geo);
+    } else {
+        // The same kernel over one run of Gaussians after the other: every per-Gaussian array is indexed from the
+        // pointer it is given, so a chunk is a launch on pointers moved to the chunk's first row.  Chunks start on
+        // workgroup boundaries: each workgroup sees the Gaussians it would see in the single launch.
+        for (int k = 0; k < plan->n; k++) {
+            const ngs_gradient_chunk& c = plan->chunks[k];
+            const size_t f = (size_t)c.first;
+            auto at = [&](const float* p, size_t per) { return p ? p + per * f : nullptr; };
+            auto to = [&](float* redirected, float* whole, size_t per) {
+                return redirected ? redirected : whole ? whole + per * f : nullptr;
+            };
+            ngs_launch_preprocess_bwd(st, c.count, D, M, means3D + 3 * f, radii + f, at(shs, (size_t)3 * M),
+                                      (const uint8_t*)(gb + gl.clamped) + f, cov3D_precomp ? nullptr : scales + 3 * f,
+                                      at(rotations, 4), at(opacities_raw, 1), scale_modifier, at(cov3D_precomp, 6), cam,
+                                      acc + (size_t)NGS_ACC_STRIDE * f, dL_dmean2D + 3 * f, to(nullptr, dL_dconic, 4),
+                                      to(c.dL_dopacity, dL_dopacity, 1), dL_dcolor + 3 * f,
+                                      to(c.dL_dmean3D, dL_dmean3D, 3), dL_dcov3D + 6 * f,
+                                      to(c.dL_dsh, dL_dsh, (size_t)3 * M), to(c.dL_dscale, dL_dscale, 3),
+                                      to(c.dL_drot, dL_drot, 4), nullptr, nullptr);
+            NGS_STAGE("preprocess backward");
+            if (plan->ready) plan->ready(plan->ctx, k);
+        }
+    }
     prof_end(ps, ST_PREPROCESS_BWD, st);
     NGS_STAGE("preprocess backward");
     return 0;
@@ -695,6 +727,51 @@ extern "C" int ngs_rasterize_backward_early_color(
                          campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix,
                          dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                          dL_drot, debug, stream, nullptr, &early);
+}
+
+extern "C" int ngs_rasterize_backward_chunked(
+    int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
+    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+    float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+    float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream, float* masked_color,
+    void (*color_ready)(void*), void* color_ready_ctx, int n_chunks, const ngs_gradient_chunk* chunks,
+    void (*chunk_ready)(void*, int), void* chunk_ready_ctx)
+{
+    const char* fn = "ngs_rasterize_backward_chunked";
+    g_err[0] = 0;
+    if (n_chunks < 1 || !chunks) return fail(fn, "missing chunks");
+    long long next = 0;
+    for (int k = 0; k < n_chunks; k++) {
+        const ngs_gradient_chunk& c = chunks[k];
+        if (c.first != next || c.count < 0 || (c.count == 0 && P != 0)) return fail(fn, "chunks must tile [0, P) in order");
+        if (c.first % NGS_GAUSS_BLOCK != 0) return fail(fn, "a chunk must start at a multiple of 256 Gaussians");
+        if ((uintptr_t)c.dL_drot % 16 != 0 || (uintptr_t)c.dL_dsh % 16 != 0)
+            return fail(fn, "a chunk's dL_drot and dL_dsh must be 16-byte aligned");
+        // an array that no chunk redirects must exist as a whole
+        if ((!c.dL_dmean3D && !dL_dmean3D) || (!c.dL_dopacity && !dL_dopacity) || (!c.dL_dscale && !dL_dscale) ||
+            (!c.dL_drot && !dL_drot))
+            return fail(fn, "missing required pointer");
+        next += c.count;
+    }
+    if (next != P) return fail(fn, "chunks must tile [0, P) in order");
+    // (backward_impl insists on the whole arrays; a caller that redirects every chunk may leave them out)
+    float* const stand_in = (float*)16;  // never dereferenced: every chunk brings its own pointer
+    auto whole = [&](float* p, bool all_redirected) { return p ? p : all_redirected ? stand_in : nullptr; };
+    bool all[4] = {true, true, true, true};
+    for (int k = 0; k < n_chunks; k++) {
+        all[0] = all[0] && chunks[k].dL_dmean3D; all[1] = all[1] && chunks[k].dL_dopacity;
+        all[2] = all[2] && chunks[k].dL_dscale; all[3] = all[3] && chunks[k].dL_drot;
+    }
+    const EarlyColor early = {masked_color, color_ready, color_ready_ctx};
+    const ChunkPlan plan = {n_chunks, chunks, chunk_ready, chunk_ready_ctx};
+    return backward_impl(fn, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales,
+                         scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
+                         radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic,
+                         whole(dL_dopacity, all[1]), dL_dcolor, whole(dL_dmean3D, all[0]), dL_dcov3D, dL_dsh,
+                         whole(dL_dscale, all[2]), whole(dL_drot, all[3]), debug, stream, nullptr,
+                         masked_color ? &early : nullptr, nullptr, nullptr, &plan);
 }
 
 extern "C" int ngs_rasterize_backward_sh_adam(int P, int D, int M, int R, const float* background, int width,

@@ -51,6 +51,7 @@ def lib():
         L.ngs_rasterize_forward_presized.restype = ctypes.c_int
         L.ngs_rasterize_backward.restype = ctypes.c_int
         L.ngs_rasterize_backward_sh_adam.restype = ctypes.c_int
+        L.ngs_rasterize_backward_chunked.restype = ctypes.c_int
         L.ngs_rasterize_forward_raw.restype = ctypes.c_int
         L.ngs_rasterize_backward_raw.restype = ctypes.c_int
         L.ngs_rasterize_backward_train.restype = ctypes.c_int
@@ -191,12 +192,20 @@ def _forward_raw(background, means3D, colors, opacity, scales, rotations, scale_
 
 
 _READY_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+_CHUNK_READY_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)
+
+
+class _GradientChunk(ctypes.Structure):  # ngs_gradient_chunk
+    _fields_ = [("first", ctypes.c_int), ("count", ctypes.c_int), ("dL_dmean3D", ctypes.c_void_p),
+                ("dL_dopacity", ctypes.c_void_p), ("dL_dscale", ctypes.c_void_p), ("dL_drot", ctypes.c_void_p),
+                ("dL_dsh", ctypes.c_void_p)]
 
 
 def rasterize_gaussians_backward_ex(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                    return_conic=False, out=None, skip_sh=False, sh_adam=None, early_color=None):
+                                    return_conic=False, out=None, skip_sh=False, sh_adam=None, early_color=None,
+                                    chunks=None):
     """``rasterize_gaussians_backward`` with what a trainer or a multi-view exchange needs on top of the reference's
     argument list.
     -> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
@@ -210,7 +219,13 @@ def rasterize_gaussians_backward_ex(background, means3D, radii, colors, scales, 
     ``early_color`` = (tensor of 3P floats, callable or None): the clamp-masked colour gradient (what
     ``masked_color_gradient`` returns) is written there as soon as the compositing stage has produced it, and the
     callable is invoked before the per-Gaussian stage is queued -- an event it records on the current stream lets
-    a collective on that data overlap with the rest of the backward pass."""
+    a collective on that data overlap with the rest of the backward pass.
+    ``chunks`` = (list of dicts, callable or None): the per-Gaussian stage is queued in that many pieces.  Each dict
+    holds ``first`` and ``count`` (the chunks tile [0, P) in order, every ``first`` a multiple of 256) and, under the
+    names dL_dmeans3D / dL_dopacity / dL_dscales / dL_drotations / dL_dsh, contiguous float32 tensors that receive
+    the chunk's rows of those gradients (all chunks must bring the same names; the whole arrays are then not
+    produced: None in their place).  The callable is invoked with the chunk's number right after its kernel has
+    been queued -- an event recorded there completes when that chunk's gradients are final."""
     _require_gpu(means3D)
     dev = means3D.device
     P = means3D.size(0)
@@ -233,21 +248,40 @@ def rasterize_gaussians_backward_ex(background, means3D, radii, colors, scales, 
             raise RuntimeError("out[%r] must be a contiguous float32 tensor with %d elements on %s" % (name, n, dev))
         return t.view(shape)
 
-    dL_dmeans3D = mk("dL_dmeans3D", (P, 3))
+    redirected = set()
+    if chunks is not None and P != 0:
+        if sh_adam is not None:
+            raise RuntimeError("chunks serve multi-view exchanges, the fused SH step single-view ones: not both")
+        per_row = dict(dL_dmeans3D=3, dL_dopacity=1, dL_dscales=3, dL_drotations=4, dL_dsh=3 * M)
+        redirected = set(k for k in chunks[0][0] if k in per_row)
+        for c in chunks[0]:
+            if set(k for k in c if k in per_row) != redirected:
+                raise RuntimeError("every chunk must redirect the same gradients")
+            for k in redirected:
+                t = c[k]
+                if t.numel() != per_row[k] * c["count"] or t.dtype != torch.float32 or t.device != dev or \
+                        not t.is_contiguous():
+                    raise RuntimeError("chunk tensor %r must be contiguous float32 with %d elements on %s"
+                                       % (k, per_row[k] * c["count"], dev))
+
+    def mk_or_chunks(name, shape):
+        return None if name in redirected else mk(name, shape)
+
+    dL_dmeans3D = mk_or_chunks("dL_dmeans3D", (P, 3))
     dL_dmeans2D = mk("dL_dmeans2D", (P, 3))
     dL_dcolors = mk("dL_dcolors", (P, NUM_CHANNELS))
     dL_dconic = mk("dL_dconic", (P, 2, 2)) if return_conic else None
-    dL_dopacity = mk("dL_dopacity", (P, 1))
+    dL_dopacity = mk_or_chunks("dL_dopacity", (P, 1))
     dL_dcov3D = mk("dL_dcov3D", (P, 6))
-    dL_dsh = None if (skip_sh or sh_adam is not None) else mk("dL_dsh", (P, M, 3))
+    dL_dsh = None if (skip_sh or sh_adam is not None) else mk_or_chunks("dL_dsh", (P, M, 3))
     if sh_adam is not None and P != 0:  # a scene pruned down to nothing has nothing to step
         if sh.numel() == 0 or M != 16:
             raise RuntimeError("the fused SH optimiser step needs SH coefficients of shape (P, 16, 3)")
         for t in (sh_adam["exp_avg"], sh_adam["exp_avg_sq"]):
             if t.shape != sh.shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
                 raise RuntimeError("Adam moments must be contiguous float32 tensors shaped like the SH coefficients")
-    dL_dscales = mk("dL_dscales", (P, 3))
-    dL_drotations = mk("dL_drotations", (P, 4))
+    dL_dscales = mk_or_chunks("dL_dscales", (P, 3))
+    dL_drotations = mk_or_chunks("dL_drotations", (P, 4))
     if early_color is not None and sh_adam is not None:
         raise RuntimeError("early_color serves multi-view exchanges, the fused SH step single-view ones: not both")
     if P != 0 and sh_adam is not None:
@@ -264,6 +298,30 @@ def rasterize_gaussians_backward_ex(background, means3D, radii, colors, scales, 
                 ctypes.c_double(sh_adam["lr_rest"]), ctypes.c_double(betas[0]), ctypes.c_double(betas[1]),
                 ctypes.c_double(sh_adam.get("eps", 1e-15)), int(sh_adam["step"]),
                 ctypes.c_float(sh_adam.get("grad_scale", 1.0)), int(bool(debug)), _stream(dev)))
+    elif P != 0 and chunks is not None:
+        masked, ready = early_color if early_color is not None else (None, None)
+        if masked is not None and (masked.numel() != 3 * P or masked.dtype != torch.float32 or masked.device != dev
+                                   or not masked.is_contiguous()):
+            raise RuntimeError("early_color[0] must be a contiguous float32 tensor with %d elements on %s" % (3 * P, dev))
+        clist, chunk_ready = chunks
+        arr = (_GradientChunk * len(clist))()
+        for k, c in enumerate(clist):
+            arr[k].first, arr[k].count = int(c["first"]), int(c["count"])
+            for field, name in (("dL_dmean3D", "dL_dmeans3D"), ("dL_dopacity", "dL_dopacity"),
+                                ("dL_dscale", "dL_dscales"), ("dL_drot", "dL_drotations"), ("dL_dsh", "dL_dsh")):
+                t = c.get(name)
+                setattr(arr[k], field, t.data_ptr() if t is not None and not (name == "dL_dsh" and skip_sh) else None)
+        cb = _READY_FN((lambda ctx: ready()) if ready is not None else 0)
+        ccb = _CHUNK_READY_FN((lambda ctx, k: chunk_ready(k)) if chunk_ready is not None else 0)
+        with torch.cuda.device(dev):
+            _check(lib().ngs_rasterize_backward_chunked(
+                P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                _ptr(scales), ctypes.c_float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                _ptr(projmatrix), _ptr(campos), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy),
+                _ptr(radii.contiguous()), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
+                int(bool(debug)), _stream(dev), _ptr(masked), cb, None, len(clist), arr, ccb, None))
     elif P != 0 and early_color is not None:
         masked, ready = early_color
         if masked.numel() != 3 * P or masked.dtype != torch.float32 or masked.device != dev or not masked.is_contiguous():

@@ -294,24 +294,30 @@ class GaussianTrainer:
         return terms["loss"], color, radii
 
     def _adam_from_exchange(self, steps, scale, sh_done, hold_opacity, densify):
-        """The optimiser kernels on the gradients the exchange holds (``scale`` turns sums over views into means)."""
+        """The optimiser kernels on the gradients the exchange holds (``scale`` turns sums over views into means),
+        run by run of Gaussians as the exchange's buffers are laid out (one run unless the exchange is chunked)."""
         it, o = self.iteration, self.opt
-        g = self.exchange.shaped()
-        m, v = self.state["xyz"]
-        _C.adam_step(self.xyz, g["dL_dmeans3D"], m, v, self.xyz_lr(it), steps["xyz"], grad_scale=scale)
-        if not sh_done:
-            m, v = self.state["features"]
-            _C.adam_step(self.features, g["dL_dsh"], m, v, o.feature_lr, steps["features"],
-                         lr_tail=o.feature_lr / 20.0, period=3 * self.M, head=3, grad_scale=scale)
         names = ("opacity_raw", "scaling_raw", "rotation_raw")
-        # a held opacity takes a step of size zero (its moments are about to be cleared by the reset that asked for it)
-        _C.adam_step_activated(
-            tuple(getattr(self, n) for n in names),
-            (g["dL_dopacity"], g["dL_dscales"], g["dL_drotations"]),
-            tuple(self.state[n][0] for n in names), tuple(self.state[n][1] for n in names),
-            (self._opacities, self._scales, self._rotations),
-            (0.0 if hold_opacity else o.opacity_lr, o.scaling_lr, o.rotation_lr),
-            tuple(max(steps[n], 1) for n in names), grad_scale=scale, densify=densify)
+        for first, count, g in self.exchange.chunk_views():
+            rows = slice(first, first + count)
+            m, v = self.state["xyz"]
+            _C.adam_step(self.xyz[rows], g["dL_dmeans3D"], m[rows], v[rows], self.xyz_lr(it), steps["xyz"],
+                         grad_scale=scale)
+            if not sh_done:
+                m, v = self.state["features"]
+                dL_dsh = g["dL_dsh"] if "dL_dsh" in g else self.exchange.dL_dsh[rows]
+                _C.adam_step(self.features[rows], dL_dsh, m[rows], v[rows], o.feature_lr, steps["features"],
+                             lr_tail=o.feature_lr / 20.0, period=3 * self.M, head=3, grad_scale=scale)
+            # a held opacity takes a step of size zero (its moments are about to be cleared by the reset that asked
+            # for it)
+            _C.adam_step_activated(
+                tuple(getattr(self, n)[rows] for n in names),
+                (g["dL_dopacity"], g["dL_dscales"], g["dL_drotations"]),
+                tuple(self.state[n][0][rows] for n in names), tuple(self.state[n][1][rows] for n in names),
+                (self._opacities[rows], self._scales[rows], self._rotations[rows]),
+                (0.0 if hold_opacity else o.opacity_lr, o.scaling_lr, o.rotation_lr),
+                tuple(max(steps[n], 1) for n in names), grad_scale=scale,
+                densify=None if densify is None else tuple(t[rows] for t in densify))
 
     def _batched_step(self, cams, gts, bg, tanfovx, tanfovy, optimize, hold_opacity, collect_stats):
         """One iteration whose loss is the mean over ``views_per_rank`` views on each of ``world`` ranks.  View k's
@@ -357,9 +363,9 @@ class GaussianTrainer:
                            lr_rest=o.feature_lr / 20.0, step=steps["features"], grad_scale=scale)
         ex.finish(scene, sh_adam=sh_adam)
         if stats and ex.stats:  # totals over every view of every rank
-            g = ex.shaped()
-            self.xyz_gradient_accum.add_(g["stat_norm"])
-            self.denom.add_(g["stat_vis"])
+            for first, count, g in ex.chunk_views():
+                self.xyz_gradient_accum[first:first + count].add_(g["stat_norm"])
+                self.denom[first:first + count].add_(g["stat_vis"])
         if optimize:
             self._adam_from_exchange(steps, scale, fused_sh, hold_opacity, None)
         return terms["loss"], color, radii

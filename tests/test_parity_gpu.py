@@ -1022,6 +1022,70 @@ def _rccl_single_rank_worker(rank, port, ret):
             ok = ok and torch.allclose(got["stat_norm"].reshape(-1), want_stats[0], rtol=1e-4, atol=1e-12)
             ok = ok and torch.equal(got["stat_vis"].reshape(-1), want_stats[1]) and torch.equal(got_max, want_max)
             ok = ok and ex.bytes_sent_per_rank() > 0
+        failed = []
+
+        def chk(label, cond):
+            if not cond:
+                failed.append(label)
+
+        # The per-Gaussian stage in runs of Gaussians, each run's slice leaving in its own collective from inside the
+        # backward pass.  First on a scene whose compositing sums have one order only (specks inside one 4x4 pixel
+        # quadrant each), so that two backward runs agree bit for bit: chunked == unchunked, exactly.
+        Ws, Hs = 1024, 768
+        Ps = (Ws // 32) * (Hs // 32)
+        g = torch.Generator().manual_seed(3)
+        cam_s = make_camera(Ws, Hs, synthetic.FOVX, (0.0, 0.0, -4.0), device=dev)
+        tsx, tsy = math.tan(cam_s.FoVx * 0.5), math.tan(cam_s.FoVy * 0.5)
+        gx, gy = torch.meshgrid(torch.arange(Ws // 32), torch.arange(Hs // 32), indexing="ij")
+        px, py = 32.0 * gx.reshape(-1) + 17.0, 32.0 * gy.reshape(-1) + 17.0
+        means = torch.stack([((2 * px + 1) / Ws - 1) * tsx * 4.0, ((2 * py + 1) / Hs - 1) * tsy * 4.0,
+                             torch.zeros(Ps)], dim=1)
+        specks = synthetic.Scene(means, torch.randn(Ps, 16, 3, generator=g) * 0.3, torch.full((Ps, 1), 0.5),
+                                 0.0005 * (1 + 0.2 * torch.rand(Ps, 3, generator=g)),
+                                 torch.nn.functional.normalize(torch.randn(Ps, 4, generator=g)), 3).to(dev)
+        dLs_ = torch.randn(3, Hs, Ws, generator=torch.Generator().manual_seed(9)).to(dev)
+        for cls in (view_parallel.FactoredGradientExchange, view_parallel.GradientBucket):
+            res = []
+            for chunks in (1, 3):
+                ex = cls(Ps, M, dev, stats=True, chunks=chunks)
+                chk(1, ex.K == chunks and ex.chunked == (chunks > 1))
+                big = torch.zeros(Ps, dtype=torch.int32, device=dev)
+                _, radii, aux = view_parallel.forward_backward(specks, cam_s, bg, lambda c: dLs_, ex, tsx, tsy,
+                                                               max_radii2D=big)
+                ex.post_view(0, specks, cam_s, aux)
+                ex.finish(specks)
+                torch.cuda.synchronize()
+                chk(2, int((radii > 0).sum()) == Ps)
+                res.append(({k: v.clone() for k, v in ex.shaped().items()}, big))
+                # the runs as the optimiser sees them: views into the buffer that tile [0, P)
+                cv = ex.chunk_views()
+                chk(3, [c[0] for c in cv] == [b[0] for b in ex.bounds] and sum(c[1] for c in cv) == Ps)
+                for first, count, d in cv:
+                    chk(4, torch.equal(d["dL_dscales"], res[-1][0]["dL_dscales"][first:first + count]))
+            for name in res[0][0]:
+                chk("%s %s: chunked differs by %g" % (cls.__name__, name,
+                                                      float((res[0][0][name] - res[1][0][name]).abs().max())),
+                    torch.equal(res[0][0][name], res[1][0][name]))
+                chk(6, (name.startswith("stat_") or float(res[0][0][name].abs().max()) > 0.0))
+            chk(7, torch.equal(res[0][1], res[1][1]) and int(res[0][1].max()) > 0)
+        # ... and on the ordinary scene, two views per step (the factored form; the dense one adds its views up
+        # locally and sends once), against the sums computed above
+        ex = view_parallel.FactoredGradientExchange(P, M, dev, stats=True, views_per_rank=2, chunks=3)
+        got_max = torch.zeros(P, dtype=torch.int32, device=dev)
+        for k, (c, g_) in enumerate(zip(cams, dLs)):
+            _, _, aux = view_parallel.forward_backward(sc, c, bg, lambda _c: g_, ex, tanx, tany, slot=k,
+                                                       max_radii2D=got_max)
+            ex.post_view(k, sc, c, aux)
+        ex.finish(sc)
+        torch.cuda.synchronize()
+        got = ex.shaped()
+        chk(8, ex.K == 3 and len(ex._pending) == 0)
+        for name in want:
+            chk(9, float((got[name] - want[name]).abs().max()) <= 2e-5 * float(want[name].abs().max()) + 1e-12)
+        chk(10, torch.allclose(got["stat_norm"].reshape(-1), want_stats[0], rtol=1e-4, atol=1e-12))
+        chk(11, torch.equal(got["stat_vis"].reshape(-1), want_stats[1]) and torch.equal(got_max, want_max))
+        ok = ok and not failed
+        ret[1] = list(failed)
         ret[0] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -1033,7 +1097,7 @@ def test_factored_exchange_over_rccl_single_rank(dgr):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_rccl_single_rank_worker, args=(33500 + os.getpid() % 2000, ret), nprocs=1, join=True)
-    assert dict(ret) == {0: True}
+    assert dict(ret) == {0: True, 1: []}
 
 
 @pytest.mark.gpu

@@ -168,6 +168,85 @@ def _multi_view_worker(rank, world, port, P, M, D, V, ret):
         dist.destroy_process_group()
 
 
+def _world8_worker(rank, world, port, P, M, D, V, chunks, ret):
+    """Eight ranks, V views each, buffers laid out in runs of Gaussians: every run of every view goes through the
+    collectives, the step's result is the sum over all world x V views run by run, the SH rebuild sees the views in
+    (slot, rank) order, and every rank contributes the same number of bytes."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def masked(geom, dL_dcolors, out=None):
+            out.copy_((dL_dcolors * geom).reshape(-1))
+            return out
+
+        seen = {}
+
+        def sh_from_views(means3D, campos, colors, degree, M_, out=None, sh_adam=None):
+            assert campos.shape == (V * world, 3) and colors.shape == (V * world, 3 * P)
+            seen["campos"] = campos.clone()
+            out.copy_(_sh_sum(means3D, campos, colors, degree, M_))
+            return out
+
+        view_parallel._C.masked_color_gradient = masked
+        view_parallel._C.sh_gradient_from_views = sh_from_views
+        means = torch.randn(P, 3, generator=torch.Generator().manual_seed(7))
+        scene = _Obj()
+        scene.means3D, scene.sh_degree = means, D
+        per_row = dict(dL_dmeans3D=3, dL_dsh=3 * M, dL_dopacity=1, dL_dscales=3, dL_drotations=4, stat_norm=1,
+                       stat_vis=1)
+
+        def value(name, view):
+            """What view ``view`` (global number) 'computed' for field ``name``, as the whole [P, w] array."""
+            w = per_row[name]
+            base = torch.arange(P * w, dtype=torch.float32).reshape(P, w)
+            return base * (view + 1) + float(sorted(per_row).index(name))
+
+        ok = True
+        for cls in (view_parallel.FactoredGradientExchange, view_parallel.GradientBucket):
+            ex = cls(P, M, torch.device("cpu"), stats=True, views_per_rank=V, chunks=chunks)
+            dense = cls is view_parallel.GradientBucket
+            want_k = 1 if dense and V > 1 else chunks  # the dense form with several views per rank sends once
+            ok = ok and ex.K == want_k and [b[0] % 256 for b in ex.bounds] == [0] * ex.K
+            ok = ok and sum(b[1] for b in ex.bounds) == P
+            for k in range(V):
+                view = rank * V + k
+                colors, mask, campos = _view_inputs(view, P)
+                cam = _Obj()
+                cam.camera_center = campos
+                if hasattr(ex, "begin_view"):
+                    assert ex.begin_view(cam, k) is None  # no hand-over on CPU tensors
+                for (first, count), cv in zip(ex.bounds, ex.slot_chunks(k)):
+                    for name, t in cv.items():
+                        t.copy_(value(name, view)[first:first + count].reshape(-1))
+                ex.post_view(k, scene, cam, dict(geom=mask, dL_dcolors=colors))
+            ex.finish(scene)
+            n_views = world * V
+            total = {name: sum(value(name, v) for v in range(n_views)) for name in ex.names}
+            sh = ex.shaped()
+            for first, count, d in ex.chunk_views():
+                for name in ex.names:
+                    ok = ok and torch.equal(d[name].reshape(count, -1), total[name][first:first + count])
+            for name in ex.names:
+                ok = ok and torch.equal(sh[name].reshape(P, -1), total[name])
+            up4 = lambda n: (n + 3) & ~3
+            fields = [per_row[n] for n in ex.names]
+            per_view = sum(sum(up4(w * count) for w in fields) for _, count in ex.bounds)
+            if dense:
+                ok = ok and ex.bytes_sent_per_rank() == 4 * per_view
+            else:
+                order = [(k, r) for k in range(V) for r in range(world)]
+                allv = [_view_inputs(r * V + k, P) for k, r in order]
+                ok = ok and torch.equal(seen["campos"], torch.stack([a[2] for a in allv]))
+                want_sh = _sh_sum(means, torch.stack([a[2] for a in allv]),
+                                  torch.stack([(a[0] * a[1]).reshape(-1) for a in allv]), D, M)
+                ok = ok and torch.equal(sh["dL_dsh"], want_sh)
+                ok = ok and ex.bytes_sent_per_rank() == 4 * V * (up4(3 * P + 3) + per_view)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
 def _densify_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -219,6 +298,32 @@ def test_two_views_per_rank_with_statistics_world2():
     port = 27500 + (os.getpid() % 2000)
     mp.spawn(_multi_view_worker, args=(world, port, P, M, D, V, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_chunked_layout_and_view_order_world8():
+    """The layout a full node uses: eight ranks, the exchange buffers in runs of Gaussians, one and two views per
+    rank and step."""
+    world, P, M, D = 8, 700, 4, 1
+    for V, chunks in ((1, 3), (2, 3)):
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        port = 25500 + (os.getpid() % 2000) + V
+        mp.spawn(_world8_worker, args=(world, port, P, M, D, V, chunks, ret), nprocs=world, join=True)
+        assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_chunk_bounds():
+    assert view_parallel.chunk_bounds(1000, 4) == [(0, 256), (256, 256), (512, 256), (768, 232)]
+    assert view_parallel.chunk_bounds(100, 4) == [(0, 100)] and view_parallel.chunk_bounds(5000, 1) == [(0, 5000)]
+    for P in (257, 1023, 1024, 1025, 3_000_000, 6_000_001):
+        for chunks in (2, 3, 4, 8):
+            b = view_parallel.chunk_bounds(P, chunks)
+            assert len(b) <= chunks and b[0][0] == 0 and sum(c for _, c in b) == P
+            assert all(f % 256 == 0 and c > 0 for f, c in b)
+            assert all(b[i][0] + b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+    per, spans, total = view_parallel.chunked_layout(("a", "b"), (3, 4), [(0, 256), (256, 5)])
+    assert per[0] == {"a": (0, 768), "b": (768, 1024)} and spans[0] == (0, 1792)
+    assert per[1] == {"a": (1792, 15), "b": (1808, 20)} and spans[1] == (1792, 36) and total == 1828
 
 
 def test_bucket_all_reduce_world2():
