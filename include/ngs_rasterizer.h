@@ -69,7 +69,8 @@ int ngs_rasterize_forward(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_a
  * count from device memory.  The host reads the count only after the last stage has been queued (for the return
  * value, and to compare it with the capacity).  If the scene produces MORE instances than the capacity, the stages
  * after the count are queued a second time with a buffer of the right size (one more call of the binning
- * allocator): the results are the same, the call is slower.  A good capacity is the previous call's count plus a
+ * allocator, made after the stream has been synchronised, so the allocator may free or move the first buffer):
+ * the results are the same, the call is slower.  A good capacity is the previous call's count plus a
  * few percent.  binning_capacity == 0 is ngs_rasterize_forward.
  */
 int ngs_rasterize_forward_presized(ngs_alloc_fn geometry_alloc, void* geometry_ctx, ngs_alloc_fn binning_alloc,
@@ -94,6 +95,10 @@ int ngs_rasterize_forward_presized(ngs_alloc_fn geometry_alloc, void* geometry_c
  * Shapes: dL_dpix [3][H][W]; dL_dmean2D [P][3]; dL_dopacity [P]; dL_dcolor
  * [P][3]; dL_dmean3D [P][3]; dL_dcov3D [P][6]; dL_dsh [P][M][3]; dL_dscale
  * [P][3]; dL_drot [P][4].
+  * The backward pass writes into geom_buffer (the gradient accumulator rows the forward pass left cleared, and the
+ * word that says whether they are clear): backward calls over one saved state must not overlap, on whatever
+ * streams; a second backward call over the same state clears the rows itself first.  A geom_buffer must come from
+ * this library's forward pass.
  */
 int ngs_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,
                            const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
@@ -389,6 +394,9 @@ int ngs_idxmap_backward(int P, int width, int height, const float* means3D, cons
  *  - Arguments as ngs_idxmap_forward without the ones the reference ignores, the workspace and the debug flag;
  *    num_rendered_device (may be NULL) is a DEVICE pointer that receives the entry count on the stream, so no host
  *    synchronisation is needed; radii may be NULL.
+  * The first call on each device resolves the array's address (under a lock; the runtime may load the code object
+ * and allocate the array then): make one call per device outside any stream capture or no-allocation region before
+ * relying on the guarantees above.  `stream` must belong to the device that is current at the call.
  */
 #define NGS_IDXMAP_STATIC_MAX_PIXELS (1 << 21)
 int ngs_idxmap_forward_static(int P, int width, int height, const float* means3D, const float* viewmatrix,

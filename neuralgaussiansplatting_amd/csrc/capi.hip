@@ -8,6 +8,7 @@
 
 #include "../../include/ngs_rasterizer.h"
 #include <chrono>
+#include <thread>
 #include "ngs_common.h"
 
 static thread_local char g_err[512] = "";
@@ -222,33 +223,37 @@ static Mailbox* mailbox_get()
     return mb.state == 1 ? &mb : nullptr;
 }
 
-// Spins until the scan kernel has posted its word.  Returns false -- the caller then falls back to a copy and a
-// stream synchronisation, which also surfaces the error of a failed kernel -- when the stream has drained or
-// failed without the word arriving, or after two seconds.
+// Waits until the scan kernel has posted its word: spinning on it for the first millisecond (a frame's scan is
+// normally done well inside that), then looking every 20 us between short sleeps, so that a long wait -- earlier work
+// still queued on the stream -- does not keep a core busy.  Returns false -- the caller then falls back to a copy and
+// a stream synchronisation, which also surfaces the error of a failed kernel -- when the stream has drained or failed
+// without the word arriving.
 static bool mailbox_wait(Mailbox* mb, hipStream_t st, uint32_t out[2])
 {
     if (!mb) return false;
+    auto take = [&](unsigned long long v) {
+        out[0] = (uint32_t)v;
+        out[1] = (uint32_t)(v >> 32);
+        return true;
+    };
+    auto stream_idle = [&]() {
+        if (hipStreamQuery(st) == hipErrorNotReady) return false;
+        (void)hipGetLastError();
+        return true;
+    };
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; spins++) {
         const unsigned long long v = __atomic_load_n(mb->host, __ATOMIC_ACQUIRE);
-        if (v != ~0ull) {
-            out[0] = (uint32_t)v;
-            out[1] = (uint32_t)(v >> 32);
-            return true;
-        }
-        if ((spins & 4095u) == 4095u) {  // every ~150 us: far beyond a healthy wait, so a normal call never pays
-            if (hipStreamQuery(st) != hipErrorNotReady) {
-                (void)hipGetLastError();
-                // finished (or failed) -- one last look, the word is written before the kernel ends
-                const unsigned long long w = __atomic_load_n(mb->host, __ATOMIC_ACQUIRE);
-                if (w == ~0ull) return false;
-                out[0] = (uint32_t)w;
-                out[1] = (uint32_t)(w >> 32);
-                return true;
-            }
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return false;
-        }
+        if (v != ~0ull) return take(v);
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
         __builtin_ia32_pause();
+    }
+    for (;;) {
+        const bool idle = stream_idle();  // looked at BEFORE the word: the word is written before the kernel ends
+        const unsigned long long v = __atomic_load_n(mb->host, __ATOMIC_ACQUIRE);
+        if (v != ~0ull) return take(v);
+        if (idle) return false;  // finished (or failed) without posting
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
 }
 
@@ -528,7 +533,10 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         }
         if (pend) pend->valid = false;
         // The estimate was too small: the stages above worked on a truncated list (inside the buffer, so harmlessly).
-        // Queue them again with a buffer that holds every instance.
+        // Queue them again with a buffer that holds every instance -- after they have drained: the allocator is about
+        // to be asked again, and one that frees or moves the first buffer at once (not in stream order) must not pull
+        // it from under kernels that are still queued.  This path is the slow one anyway.
+        NGS_HIP(hipStreamSynchronize(st));
         capacity = (int64_t)host_misc[0];
     }
     if (num_rendered) *num_rendered = (int)host_misc[0];

@@ -18,7 +18,10 @@
 #define NGS_ACC_STRIDE 16    // floats per Gaussian in the 64-byte gradient accumulator rows
 #define NGS_ALIGN 256
 
-// Words of the geometry buffer's `misc` array beyond [0] (instance count) and [1] (error flags).
+// Words of the geometry buffer's `misc` array beyond [0] (instance count) and [1] (flags: 1 = a Gaussian was culled
+// although the caller said `prefiltered`, 2 = more than 2^31-1 instances, both written by the scan kernel; 4 = an
+// emission pass met more instances than the binning buffer's capacity and was cut short -- informational: the host
+// decides from the count, queues the stages again with a buffer that fits, and the bit stays set).
 #define NGS_MISC_DMIN 2       // lower bound of the visible Gaussians' depth bits
 #define NGS_MISC_DMAX 3       // upper bound
 #define NGS_MISC_ACC_CLEAN 4  // 1: the gradient accumulator rows are all zero (the forward pass left them so)

@@ -29,7 +29,7 @@ struct Api {
 // nearly the same number of instances, so the next call sizes its binning buffer from it up front and the library
 // queues every stage without waiting for its own count (ngs_rasterize_forward_presized).
 std::mutex hint_mutex;
-std::map<std::tuple<int, int, int>, std::pair<long long, long long>> instance_hint;
+std::map<std::tuple<int, int, int, int>, std::pair<long long, long long>> instance_hint;
 long long forced_capacity = -1;  // tests: >= 0 replaces the estimate (0 = wait for the count, as the reference does)
 
 template <typename F>
@@ -111,7 +111,8 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
                                torch::zeros({0}, means.options().dtype(torch::kInt32)), geom, binning, img);
     }
     long long capacity = 0;
-    const auto key = std::make_tuple((int)dev.index(), W, H);
+    // (two scenes of one resolution that alternate in a process keep their own estimates unless their sizes are close)
+    const auto key = std::make_tuple((int)dev.index(), W, H, 31 - __builtin_clz((unsigned)std::max(P, 1)));
     {
         std::lock_guard<std::mutex> lock(hint_mutex);
         const auto it = instance_hint.find(key);

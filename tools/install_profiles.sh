@@ -5,10 +5,13 @@ set -e
 TAG=${1:-r01}
 SRC=gpurun_out/final
 # results of earlier collections pile up next to the newest (every run's files carry its process id): keep the newest
-for d in $SRC/trace $SRC/trace_hot $SRC/pmc_fetch $SRC/pmc_write $SRC/pmc_valu; do
-    for sub in $d/*/; do
-        newest=$(ls -t $sub | head -1 | sed 's/_.*//')
-        find $sub -type f ! -name "${newest}_*" -delete
+for d in "$SRC/trace" "$SRC/trace_hot" "$SRC/pmc_fetch" "$SRC/pmc_write" "$SRC/pmc_valu"; do
+    [ -d "$d" ] || continue
+    for sub in "$d"/*/; do
+        [ -d "$sub" ] || continue
+        newest=$(ls -t "$sub" | head -1 | sed 's/_.*//')
+        [ -n "$newest" ] || continue
+        find "$sub" -type f ! -name "${newest}_*" -delete
     done
 done
 for c in c1 c2 c3 c4 c5; do cp $SRC/${c}_bench.json profiles/${TAG}_${c}_bench.json; done
@@ -25,5 +28,5 @@ if [ -d $SRC/trace_hot ]; then
 fi
 python3 tools/pmc_summary.py --fetch $SRC/pmc_fetch --write $SRC/pmc_write --config c4 \
     --out profiles/hbm_traffic.json --raw profiles/${TAG}_c4_pmc_traffic.json
-python3 tools/pmc_valu_summary.py $SRC/pmc_valu profiles/valu_issue.json c4 profiles/${TAG}_c4_valu.md > profiles/${TAG}_c4_valu.md
+python3 tools/pmc_valu_summary.py $SRC/pmc_valu profiles/valu_issue.json c4 "rocprofv3 --pmc SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" > profiles/${TAG}_c4_valu.md
 python3 tools/results_tables.py $TAG
