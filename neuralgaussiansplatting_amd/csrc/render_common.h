@@ -102,6 +102,9 @@ __device__ __forceinline__ int tile_local_y(int tid)
 // Arguments far below the range are harmless: exp2 underflows to zero and alpha fails the 1/255 test.
 __device__ __forceinline__ float exp_nonpos(float x)
 {
+#ifdef NGS_LIBRARY_EXP  // measurements only: the device library's expf in both compositing kernels
+    return expf(x);
+#endif
     const float log2e_hi = __builtin_bit_cast(float, 0x3fb8aa3bu), log2e_lo = __builtin_bit_cast(float, 0x32a5705fu);
     const float ph = x * log2e_hi;
     const float d = fmaf(x, log2e_lo, fmaf(x, log2e_hi, -ph));

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
 cd $ROOT
-for c in c4 c1 c2 c3 c5; do
+for c in c4 c4s c1 c2 c3 c5; do
     timeout -k 10 300 python3 bench.py --config $c > $OUT/${c}_bench.json 2> $OUT/${c}_bench.err
     echo "bench $c done"
 done
@@ -22,8 +22,8 @@ timeout -k 10 300 python3 bench.py --no-idxmap --no-cpu-baseline --views-per-gpu
 echo "training variants done"
 timeout -k 10 600 python3 tools/footprint_sweep.py $OUT/c4_footprint.json > $OUT/footprint.log 2>&1
 echo "footprint sweep done"
-timeout -k 10 300 python3 tools/train_demo.py --iterations 7000 --gt 150000 --init 30000 --views 100 --out $OUT/train_demo.json > /dev/null 2> $OUT/train_demo.err
-echo "training run done"
+timeout -k 10 600 python3 tools/footprint_sweep.py $OUT/c4s_footprint.json --config c4s > $OUT/footprint_c4s.log 2>&1
+echo "footprint sweep of the trained-scene-like workload done"
 cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
@@ -32,6 +32,8 @@ echo "trace done"
 # are to be held against (in the full run the training iterations' launches of the same kernels are averaged in)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_hot -- python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-idxmap --train-steps 0 > $OUT/trace_hot.log 2>&1
 echo "hot-path trace done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_hot_c4s -- python3 $ROOT/bench.py --config c4s --steps 30 --warmup 12 --no-cpu-baseline --no-idxmap --train-steps 0 --no-stage-timing --repeats 1 > $OUT/trace_hot_c4s.log 2>&1
+echo "hot-path trace of the trained-scene-like workload done"
 PMC_CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --train-steps 0 --no-idxmap --no-cpu-baseline"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMC_CMD > $OUT/pmc_fetch.log 2>&1
 echo "fetch done"

@@ -31,6 +31,7 @@ def main():
                      "last_contributor_per_pixel_mean": d["config"]["last_contributor_per_pixel_mean"],
                      "ms_per_step": d["ms_per_step"], "Mpixels_per_s": d["value"], "iters_per_s": d["iters_per_s"],
                      "train_iters_per_s": d["train"]["iters_per_s"] if d.get("train") else None,
+                     "depth_order": d.get("depth_order"),
                      "stages_ms": {k: v["ms"] for k, v in d["stages"].items()}})
         print(json.dumps(rows[-1]), flush=True)
     with open(out, "w") as f:
