@@ -377,6 +377,39 @@ def test_crowded_tiles_take_the_long_segment_path(dgr, oracle, depth_order):
     check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=32.0 * 32.0)
 
 
+@pytest.mark.parametrize("layout", ["one_plane", "three_planes", "forty_planes", "planes_and_spread", "beyond_the_split"])
+def test_long_lists_with_crowded_depths(layout, dgr, oracle, depth_order):
+    """Tile lists far beyond what one workgroup sorts, with depths that crowd: all on one plane (nothing to sort,
+    index order), on three planes (depth groups too large to split: the general kernel), on forty planes (the split's
+    sub-lists hold a few distinct depths each, ties in index order), planes mixed with spread-out depths, and a list
+    longer than the split takes at all."""
+    if layout == "beyond_the_split" and depth_order != "by_tile":
+        pytest.skip("one run of the half-million-entry list is enough")
+    P, W, H = (24000, 32, 32) if layout != "beyond_the_split" else (540_000, 16, 16)
+    c = case(P=P, W=W, H=H, D=0, seed=53, log_scale=(-5.0, -4.0) if P < 100_000 else (-4.0, -3.5),
+             extent=(0.5, 0.5, 1.3) if P < 100_000 else (0.2, 0.2, 1.3))
+    z = c["scene"].means3D[:, 2]
+    n = z.shape[0]
+    g = torch.Generator().manual_seed(7)
+    if layout == "one_plane":
+        z[:] = 0.25
+    elif layout == "three_planes":
+        z[:] = torch.tensor([0.0, 0.25, 0.5])[torch.randint(0, 3, (n,), generator=g)]
+    elif layout == "forty_planes":
+        z[:] = (torch.randint(0, 40, (n,), generator=g).float() - 20.0) / 32.0
+    elif layout == "planes_and_spread":
+        on_plane = torch.rand(n, generator=g) < 0.5
+        z[on_plane] = (torch.randint(0, 6, (int(on_plane.sum()),), generator=g).float() - 3.0) / 8.0
+    o = oracle_forward(oracle, c)
+    per_tile = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert per_tile.max() > (4096 if layout != "beyond_the_split" else 524288)
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(12))
+    h = run_hip(dgr, c, dL_dpix=dL)
+    check_forward(o, h, exact_pixels=False)
+    if layout != "beyond_the_split":
+        check_grads(h["grads"], oracle_backward(oracle, c, o, dL), scale=float(W * H))
+
+
 @pytest.mark.parametrize("name", ["sh3_64x64", "big_splats", "crowded"])
 def test_presized_binning_buffer_any_capacity_same_result(name, dgr, oracle, depth_order):
     """The forward pass with the binning buffer sized from an estimate before the count is known: whatever the
