@@ -460,7 +460,8 @@ void ngs_debug_depth_order(int choice);
 int ngs_debug_depth_order_taken(void);
 /*
  * What the default choice goes by: the device clocks the stages between the scan and the compositing kernel on every
- * frame, and the library keeps, per calling thread and device and for the current (width, height, P), the last three
+ * frame, and the library keeps, per calling thread and device and for the current width, height and P (to within a factor
+ * of two), the last three
  * such durations with either source of the depth order; once both have three, the one with the cheaper best frame
  * (per instance) is taken and the other tried again every 128 frames (every 1024 when it was more than a quarter behind).  Returns those two durations in
  * microseconds as of the last forward call of the calling thread on the current device (-1: not measured yet);

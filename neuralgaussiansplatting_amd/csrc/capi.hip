@@ -364,7 +364,9 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
     Mailbox* mb = mailbox_get();
     RouteHistory* rh = mb ? &mb->route : nullptr;
     if (rh) {
-        if (rh->W != width || rh->H != height || rh->P != P) {
+        // (a scene that grows or shrinks, as one does under densification, keeps its history until its size has
+        // changed by a factor of two: the figures are per instance)
+        if (rh->W != width || rh->H != height || P > 2LL * rh->P || 2LL * P < rh->P) {
             const double rate = rh->ticks_per_us;
             const uint32_t seq = rh->seq;
             memset(rh, 0, sizeof *rh);
