@@ -4,9 +4,13 @@
  * library is compared against (tests/, the smoke check and the benchmark's
  * cpu_baseline leg).  Nothing in the shipped package may call it.
  *
- * PARITY STATUS: the SH->RGB stage is pinned by fixtures generated from the
- * reference's own Python (utils/sh_utils.py:57-112) and the camera matrices by
- * utils/graphics_utils.py:38-71; every other stage is "parity unpinned": the
+ * PARITY STATUS: pinned by fixtures generated from the reference's own Python:
+ * the SH->RGB stage and its backward (utils/sh_utils.py:57-112), the 3D
+ * covariance from scale and rotation and its backward
+ * (scene/gaussian_model.py:29-33 over utils/general_utils.py:64-110), and the
+ * camera matrices (utils/graphics_utils.py:38-71).  Every other stage --
+ * screen-space covariance, conic and radius, binning, compositing and their
+ * backward -- is "parity unpinned": the
  * reference ships no tests or golden vectors for it and its CUDA sources
  * cannot be compiled here (they need the CUDA toolkit headers and CUB).  Those
  * stages are cross-checked by an independent PyTorch-autograd formulation and
