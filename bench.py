@@ -144,6 +144,10 @@ def main():
     ap.add_argument("--stage-steps", type=int, default=None,
                     help="steps of the separate loop that times the stages with HIP events (default min(--steps, 30)); "
                          "the headline loop runs without them")
+    ap.add_argument("--depth-order", default="auto", choices=("auto", "per_tile_sort", "gaussians_first"),
+                    help="where the depth order of the tile lists comes from: chosen by the library from what either "
+                         "has cost (default), or forced (counter and trace runs, whose few frames would otherwise "
+                         "mix the two while the library is still trying both)")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
@@ -223,6 +227,8 @@ def main():
         if args.verbose:
             print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
 
+    if args.depth_order != "auto":
+        _C.lib().ngs_debug_depth_order({"per_tile_sort": 0, "gaussians_first": 1}[args.depth_order])
     note("scene and view resident")
     for i in range(max(args.warmup, 1)):
         color, radii, aux = step()
@@ -250,7 +256,7 @@ def main():
     note("timed steps done")
     # which of the two sources of the depth order the library took for this workload, and what the other one costs
     depth_order = None
-    if world == 1 and V == 1 and not args.no_stage_timing:
+    if world == 1 and V == 1 and not args.no_stage_timing and args.depth_order == "auto":
         L = _C.lib()
         L.ngs_debug_depth_order_taken.restype = ctypes.c_int
         taken = int(L.ngs_debug_depth_order_taken())

@@ -23,11 +23,11 @@ cp $SRC/trace/*/*_kernel_stats.csv profiles/${TAG}_c4_final_kernel_stats.csv
 python3 tools/kernel_stats_md.py profiles/${TAG}_c4_final_kernel_stats.csv "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline" > profiles/${TAG}_c4_final_kernel_stats.md
 if [ -d $SRC/trace_hot ]; then
     cp $SRC/trace_hot/*/*_kernel_stats.csv profiles/${TAG}_c4_hot_path_kernel_stats.csv
-    python3 tools/kernel_stats_md.py profiles/${TAG}_c4_hot_path_kernel_stats.csv "python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-idxmap --train-steps 0" > profiles/${TAG}_c4_hot_path_kernel_stats.md
+    python3 tools/kernel_stats_md.py profiles/${TAG}_c4_hot_path_kernel_stats.csv "python3 bench.py --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-idxmap --train-steps 0 --depth-order per_tile_sort" > profiles/${TAG}_c4_hot_path_kernel_stats.md
 fi
 if [ -d $SRC/trace_hot_c4s ]; then
     cp $SRC/trace_hot_c4s/*/*_kernel_stats.csv profiles/${TAG}_c4s_hot_path_kernel_stats.csv
-    python3 tools/kernel_stats_md.py profiles/${TAG}_c4s_hot_path_kernel_stats.csv "python3 bench.py --config c4s --steps 30 --warmup 12 --no-cpu-baseline --no-idxmap --train-steps 0 --no-stage-timing --repeats 1" > profiles/${TAG}_c4s_hot_path_kernel_stats.md
+    python3 tools/kernel_stats_md.py profiles/${TAG}_c4s_hot_path_kernel_stats.csv "python3 bench.py --config c4s --steps 30 --warmup 5 --no-cpu-baseline --no-idxmap --train-steps 0 --repeats 1 --depth-order gaussians_first" > profiles/${TAG}_c4s_hot_path_kernel_stats.md
 fi
 python3 tools/pmc_summary.py --fetch $SRC/pmc_fetch --write $SRC/pmc_write --config c4 \
     --out profiles/hbm_traffic.json --raw profiles/${TAG}_c4_pmc_traffic.json

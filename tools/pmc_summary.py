@@ -25,7 +25,8 @@ STAGE_KERNELS = {
     "duplicate_with_keys": ["duplicate_kernel"],
     "radix_sort_tile_bits": ["sort_hist_kernel", "sort_scan_kernel", "sort_scatter_kernel"],
     "tile_ranges": ["tile_ranges_kernel"],
-    "segment_sort_depth": ["segment_sort_bucket_kernel", "segment_sort_long_kernel"],
+    "segment_sort_depth": ["segment_sort_bucket_kernel", "segment_split_kernel", "segment_sort_sub_kernel",
+                           "segment_sort_long_kernel"],
     "depth_sort_gaussians": ["depth_order_kernel"],  # its radix passes are counted under radix_sort_tile_bits
     "render_fwd": ["render_fwd_kernel"],
     "render_bwd": ["render_bwd_kernel"],
