@@ -7,7 +7,8 @@ bit-exact; rendered RGB is within 1e-5 abs; gradients of a loss with
 dL/dpixel ~ N(0,1)/(W*H) are within 1e-5 abs.  For an un-normalised
 dL/dpixel ~ N(0,1): the BASELINE configurations at full size (c2..c5 and the
 trained-scene-like c4s) hold every gradient tensor within 5e-6 of its largest
-element with no absolute allowance (check_grads_full_size); the small cases
+element with no absolute allowance, rows of Gaussians under a counted
+knife-edge pixel aside (check_grads_full_size); the small cases
 and random sweeps use 2e-4 of the largest element plus a floor for tensors
 that are tiny throughout (check_grads).
 """
@@ -155,9 +156,14 @@ def check_grads(hg, og, scale=1.0, knife_edge_pixels=0):
 
 
 # The bar of the full-size configurations: every gradient tensor within this fraction of its largest element
-# (observed: at most 1e-6), with no absolute allowance; ten times that only on the rows of Gaussians that are
-# listed for a tile in which check_forward flagged a pixel.
+# (observed: at most 1e-6), with no absolute allowance -- except on the rows of the Gaussians that are listed for a
+# tile in which check_forward flagged a pixel (a few hundred rows of 10^5 .. 10^6).  There the two implementations
+# blended a different set of splats at one pixel, and the rows differ by what that pixel hands them: the splat on the
+# threshold (alpha = 1/255, G = alpha / opacity) receives or loses G dL/dalpha ~ 4e-3 / opacity times |dL/dpixel| in
+# its opacity gradient, and every splat behind it at that pixel is scaled by 1 - alpha.  With dL/dpixel ~ N(0, 1)
+# and tensors whose largest elements are ~10 that is up to ~1e-3 of the largest element (observed: 4.8e-5 at C2).
 FULL_SIZE_GRAD_REL_TO_MAX = 5e-6
+KNIFE_EDGE_ROWS_REL_TO_MAX = 2e-3
 
 
 def check_grads_full_size(hg, og, o, edge, W, H, bar=None):
@@ -177,7 +183,8 @@ def check_grads_full_size(hg, og, o, edge, W, H, bar=None):
         worst[name] = max(clean, edgy) / big
         assert big > 0.0, name
         assert clean <= bar * big, "%s: max err %g vs max magnitude %g (%.2e of it)" % (name, clean, big, clean / big)
-        assert edgy <= 10.0 * bar * big, "%s under knife-edge pixels: max err %g vs %g" % (name, edgy, big)
+        assert edgy <= max(KNIFE_EDGE_ROWS_REL_TO_MAX, 10.0 * bar) * big, "%s under knife-edge pixels: max err %g vs %g" % (
+            name, edgy, big)
         # the stated bar for a loss normalised by the pixel count, as the reference's is: 1e-5 absolute, relative to
         # the tensor's largest element where that exceeds 1
         assert max(clean, edgy) / (W * H) <= GRAD_ATOL * max(1.0, big / (W * H)), name

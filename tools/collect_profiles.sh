@@ -44,6 +44,7 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_SAL
 echo "valu done"
 # The counter tables above belong to this build: summarise them (tools/install_profiles.sh does the same at home), then
 # take the headline lines once more so that their roofline objects quote this build's own traffic and issue figures.
+cd $ROOT
 if python3 tools/pmc_summary.py --fetch $OUT/pmc_fetch --write $OUT/pmc_write --config c4 --out $ROOT/profiles/hbm_traffic.json --raw $OUT/c4_pmc_traffic.json > $OUT/pmc_summary.log 2>&1 \
    && python3 tools/pmc_valu_summary.py $OUT/pmc_valu $ROOT/profiles/valu_issue.json c4 "rocprofv3 --pmc (collect_profiles.sh)" > $OUT/c4_valu.md 2>> $OUT/pmc_summary.log; then
     cd $ROOT
