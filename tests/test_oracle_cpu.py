@@ -133,6 +133,29 @@ def test_python_cov3d_branch_matches_reference(mi):
     np.testing.assert_allclose(r.grad.numpy(), wr, rtol=0, atol=2e-6 * float(np.abs(wr).max()))
 
 
+def test_wide_sums_are_the_same_terms_summed_in_double(oracle):
+    """The checker's yardstick mode (running sums of the compositing backward held in double precision) adds the
+    very terms of the float32 mode: on a scene whose sums have a few terms each the two agree to float32 rounding,
+    and on a scene with splats hundreds of pixels wide the float32 sums drift away from the wide ones by more than
+    that -- which is what the mode is for."""
+    dL = torch.randn(3, 48, 64, generator=torch.Generator().manual_seed(3))
+    small = case(P=300, W=64, H=48, D=1, M=4, seed=5)
+    big = case(P=300, W=64, H=48, D=1, M=4, seed=5, log_scale=(-1.2, -0.6))
+    drift = []
+    for c in (small, big):
+        o = oracle_forward(oracle, c)
+        a = oracle_backward(oracle, c, o, dL)
+        b = oracle_backward(oracle, c, o, dL, wide_sums=True)
+        worst = 0.0
+        for k in a:
+            big_el = float(np.abs(b[k]).max())
+            assert big_el > 0.0 and np.isfinite(b[k]).all(), k
+            worst = max(worst, float(np.abs(a[k] - b[k]).max()) / big_el)
+        drift.append(worst)
+    assert drift[0] < 2e-6, drift
+    assert drift[1] < 1e-4 and drift[1] > drift[0], drift
+
+
 def test_camera_matrices_match_reference_graphics_utils():
     """Fixture made from utils/graphics_utils.py + the scene/cameras.py:54-57 recipe of the reference."""
     from neuralgaussiansplatting_amd.cameras import projection_matrix, world_to_view
