@@ -175,6 +175,7 @@ struct RouteHistory {
     double per_instance[2][3];   // the last three measurements per route, in us per instance
     int measured[2];             // how many there have been (the first frames of a process run slow: one is not enough)
     int age[2];                  // decisions since route r was last taken
+    int decisions;               // decisions since the history was started
     double ticks_per_us;
 };
 struct Mailbox {
@@ -393,17 +394,24 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         const int by_model = model[1] < model[0] ? 1 : 0;
         if (!rh || inst <= 0.0) return by_model == 1;
         int pick;
+        rh->decisions += rh->decisions < (1 << 30);
         if (rh->measured[0] == 0 && rh->measured[1] == 0) {
             pick = by_model;
-        } else if (rh->measured[0] < 3 || rh->measured[1] < 3) {
+        } else if ((rh->measured[0] < 3 || rh->measured[1] < 3) && rh->decisions <= 24) {
             // three frames with either before the figures count (a frame's figure reaches the host a call later, so
-            // a source may get a frame or two more than that)
+            // a source may get a frame or two more than that; and should figures keep getting lost, the trying ends
+            // after two dozen frames)
             pick = rh->measured[0] == rh->measured[1] ? by_model : rh->measured[1] < rh->measured[0] ? 1 : 0;
+        } else if (rh->measured[0] == 0 || rh->measured[1] == 0) {
+            pick = by_model;
         } else {
             // the smallest of the last three measurements: a frame that was held up says nothing about its source
             double est[2];
-            for (int r = 0; r < 2; r++)
-                est[r] = inst * fmin(rh->per_instance[r][0], fmin(rh->per_instance[r][1], rh->per_instance[r][2]));
+            for (int r = 0; r < 2; r++) {
+                double best_r = rh->per_instance[r][0];
+                for (int k = 1; k < 3 && k < rh->measured[r]; k++) best_r = fmin(best_r, rh->per_instance[r][k]);
+                est[r] = inst * best_r;
+            }
             const int best = est[1] < est[0] ? 1 : 0, other = 1 - best;
             pick = ++rh->age[other] >= (est[other] < 1.25 * est[best] ? 128 : 1024) ? other : best;
         }

@@ -4,7 +4,7 @@
 // stage into LDS.  Follows cuda_rasterizer/forward.cu:155-256 and
 // auxiliary.h:41-56,139-164 of the reference.  Built with -ffp-contract=off:
 // radii, rectangles and depth bits must equal the CPU checker's exactly.
-#include "ngs_common.h"
+#include "render_common.h"
 
 // auxiliary.h:41-44 (double arithmetic, rounded once to float)
 __device__ __forceinline__ float ndc_to_pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
@@ -222,9 +222,10 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
             col = sh_to_rgb_last8(part, (const float3*)e_sh, d, cb);
             // the record is parked in this lane's (now consumed) LDS slots and leaves with the wave's other records
             // as coalesced 1-KiB stores below
+            const float3 cull = record_cull_terms(con_x, con_y, con_z, e_op);
             wslots[0 * SH_SLOT + lane] = make_float4(ix, iy, con_x, con_y);
             wslots[1 * SH_SLOT + lane] = make_float4(con_z, e_op, col.x, col.y);
-            wslots[2 * SH_SLOT + lane] = make_float4(col.z, 0.0f, 0.0f, 0.0f);
+            wslots[2 * SH_SLOT + lane] = make_float4(col.z, cull.x, cull.y, cull.z);
             wslots[3 * SH_SLOT + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     } else if (live) {
@@ -238,8 +239,10 @@ __global__ __launch_bounds__(NGS_GAUSS_BLOCK) void preprocess_fwd_kernel(
         }
         float4* r = rec + 4 * (size_t)idx;
         r[0] = make_float4(ix, iy, con_x, con_y);
-        r[1] = make_float4(con_z, raw ? sigmoid_act(opac[idx]) : opac[idx], col.x, col.y);
-        r[2] = make_float4(col.z, 0.0f, 0.0f, 0.0f);
+        const float op = raw ? sigmoid_act(opac[idx]) : opac[idx];
+        const float3 cull = record_cull_terms(con_x, con_y, con_z, op);
+        r[1] = make_float4(con_z, op, col.x, col.y);
+        r[2] = make_float4(col.z, cull.x, cull.y, cull.z);
     }
     if (live) {
         depth[idx] = view_z;

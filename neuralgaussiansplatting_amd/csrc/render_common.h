@@ -37,6 +37,16 @@ __device__ __forceinline__ bool splat_reaches(float sx, float sy, float a, float
     return 0.5f * qmin <= tau + 0.01f + 1e-5f * mag;
 }
 
+// What a splat record carries for the compositing kernels' first, cheap test of a (splat, pixel block) pair:
+// x = tau = ln(255 opacity); y = a - b^2 / c and z = c - b^2 / a, the factors by which the quadratic form grows with
+// dx^2 alone and with dy^2 alone whatever the other coordinate does (the minimum of q over dy for a given dx is
+// dx^2 (a - b^2 / c)).  Zero factors for a conic that is not positive definite: such a splat is never culled.
+__device__ __forceinline__ float3 record_cull_terms(float a, float b, float c, float opacity)
+{
+    const bool pd = a > 0.0f && c > 0.0f && a * c - b * b > 0.0f;
+    return make_float3(splat_tau(opacity), pd ? a - b * b / c : 0.0f, pd ? c - b * b / a : 0.0f);
+}
+
 // The same test for the four 4x4 quadrants of an 8x8 block at once (corner pixel (bx0, by0)); bit k of the result
 // is quadrant (k & 1, k >> 1).  The quadrants share their edge lines, so the sixteen clamped parabola minima are
 // formed from four x offsets and four y offsets; the unclamped minimisers use reciprocals instead of divisions (an
