@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
     const float* __restrict__ dL_dpix, float* __restrict__ acc, uint32_t* __restrict__ misc)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) misc[NGS_MISC_ACC_CLEAN] = 0u;  // the rows are about to be used
-    // record k: [0] = {x, y, ln(255 opacity), -}, [1] = {conic a, b, c, opacity}, [2] = {r, g, b, Gaussian id bits}
+    // record k: [0] = {x, y, conic a, c}, [1] = {conic b, opacity, ln(255 opacity), -}, [2] = {r, g, b, Gaussian id bits}
     __shared__ float4 s_rec[BWD_BATCH][3];
     // One table of sums per wave: a wave's LDS operations complete in order, so it adds to its own table with a plain
     // read, add and write.  An LDS float atomic costs about three cycles of the CU's LDS per active lane, ten times
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
     v2f rec_rg = {0.0f, 0.0f};
     float rec_b = 0.0f;
     const v2f dp_rg = {dpr, dpg};
+    const v2f pix = {pxf, pyf};
     // After the reduce-scatter the even lanes of a row hold partials 0..7 (index bits taken from lane bits 3, 2, 1
     // in that order of significance 1, 2, 4) and the odd lanes partial 8; lane 1 speaks for the odd ones.
     const bool up8 = (li & 8) != 0, up4 = (li & 4) != 0, up2 = (li & 2) != 0, up1 = (li & 1) != 0;
@@ -162,10 +163,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
             const float4* gr = splat_rec + 4 * (size_t)id;  // one 64-byte line per splat
             const float4 a = gr[0];
             const float4 b = gr[1];
-            const float c = gr[2].x;
-            s_rec[tid][0] = make_float4(a.x, a.y, splat_tau(b.y), 0.0f);
-            s_rec[tid][1] = make_float4(a.z, a.w, b.x, b.y);
-            s_rec[tid][2] = make_float4(b.z, b.w, c, __uint_as_float(id));
+            const float4 c = gr[2];  // {blue, ln(255 opacity), -, -}
+            s_rec[tid][0] = make_float4(a.x, a.y, a.z, b.x);
+            s_rec[tid][1] = make_float4(a.w, b.y, c.y, 0.0f);
+            s_rec[tid][2] = make_float4(b.z, b.w, c.x, __uint_as_float(id));
         }
         static_assert(sizeof(s_acc) % sizeof(float4) == 0, "the tables are cleared with 16-byte stores");
 #pragma unroll
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
                 const uint32_t pos = (uint32_t)(first - mine);
                 const float4 p = s_rec[mine][0];
                 const float4 q = s_rec[mine][1];
-                const unsigned bits = splat_reaches_quadrants(p.x, p.y, q.x, q.y, q.z, p.z, bx0, by0);
+                const unsigned bits = splat_reaches_quadrants(p.x, p.y, p.z, q.x, p.w, q.z, bx0, by0);
                 r0 = pos < qmax0 && (bits & 1u);
                 r1 = pos < qmax1 && (bits & 2u);
                 r2 = pos < qmax2 && (bits & 4u);
@@ -228,11 +229,18 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
         // One step of a row: splat `j` of the batch (record p, q, col) against the row's 16 pixels.
         auto step = [&](const int it, const int j, const float4 p, const float4 q, const float4 col, const bool shared) {
             const bool have = it < my_n;
-            const float dx = p.x - pxf, dy = p.y - pyf;
-            // same evaluation order as the forward pass (and the reference): alpha must come out bit-identical
-            const float power = -0.5f * (q.x * dx * dx + q.z * dy * dy) - q.y * dx * dy;
+            // same evaluation order as the forward pass (and the reference): alpha must come out bit-identical;
+            // the two squares as a pair (packed FP32: same roundings, half the issue slots)
+            const v2f d = (v2f){p.x, p.y} - pix;
+            const v2f sq = ((v2f){p.z, p.w} * d) * d;  // {a dx dx, c dy dy}
+            const float dx = d.x, dy = d.y;
+            float sum = sq.x + sq.y;
+            asm("" : "+v"(sum));  // the rest one by one (left alone, the compiler pairs it up with register moves)
+            float half = -0.5f * sum;
+            asm("" : "+v"(half));
+            const float power = half - q.x * dx * dy;
             const float G = exp_nonpos(power);
-            const float alpha = fminf(0.99f, q.w * G);
+            const float alpha = fminf(0.99f, q.y * G);
             // first - j is the reference's `contributor` after its decrement; the pixel blended the splat if that
             // lies below its last contributor, i.e. if j lies above `behind`.  The alpha test comes last and on its
             // own, so that the wave's mask of live lanes is that comparison's result as it stands.
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
             // opacity, which turn them into the gradients of its position, conic and opacity, are the same for every
             // pixel and are applied once per splat when the batch is flushed.
             const float g = live ? G * dL_dalpha : 0.0f;
-            const float go = q.w * g;  // dL/dG
+            const float go = q.y * g;  // dL/dG
             const float m1x = go * dx, m1y = go * dy;
             const float m2xx = m1x * dx, m2xy = m1x * dy, m2yy = m1y * dy;
             const v2f v67 = w * dp_rg;  // ACC_R, ACC_G

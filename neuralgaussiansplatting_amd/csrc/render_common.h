@@ -47,41 +47,47 @@ __device__ __forceinline__ float3 record_cull_terms(float a, float b, float c, f
     return make_float3(splat_tau(opacity), pd ? a - b * b / c : 0.0f, pd ? c - b * b / a : 0.0f);
 }
 
-// The same test for the four 4x4 quadrants of an 8x8 block at once (corner pixel (bx0, by0)); bit k of the result
-// is quadrant (k & 1, k >> 1).  The quadrants share their edge lines, so the sixteen clamped parabola minima are
-// formed from four x offsets and four y offsets; the unclamped minimisers use reciprocals instead of divisions (an
-// error of an ulp in the minimiser's position moves the minimum by a second-order amount), and the margin uses the
-// block's extents, which are at least the quadrant's.
+// The same test for the four 4x4 quadrants of an 8x8 block (corner pixel (bx0, by0); bit k of the
+// result is quadrant (k & 1, k >> 1)), from the edges that FACE the splat's centre only: the form is convex with its
+// minimum at the centre, so from the point of a rectangle where it is smallest the way to the centre leaves the
+// rectangle at once -- that point lies on an edge whose outward side the centre is on.  Per axis a quadrant has at
+// most one such edge (none when the centre lies within the quadrant's extent along that axis), and the quadrants of
+// a column (row) share it: four edge lines, each against two extents, instead of eight.  The unclamped minimisers use reciprocals instead of
+// divisions, and the margin uses the block's extents, which are at least the quadrant's.
 __device__ __forceinline__ unsigned splat_reaches_quadrants(float sx, float sy, float a, float b, float c, float tau,
-                                                            float bx0, float by0)
+                                                          float bx0, float by0)
 {
     if (!(a > 0.0f && c > 0.0f && a * c - b * b > 0.0f)) return 0xfu;
-    const float ex[4] = {bx0 - sx, (bx0 + 3.0f) - sx, (bx0 + 4.0f) - sx, (bx0 + 7.0f) - sx};
-    const float ey[4] = {by0 - sy, (by0 + 3.0f) - sy, (by0 + 4.0f) - sy, (by0 + 7.0f) - sy};
+    const float X[4] = {bx0 - sx, (bx0 + 3.0f) - sx, (bx0 + 4.0f) - sx, (bx0 + 7.0f) - sx};
+    const float Y[4] = {by0 - sy, (by0 + 3.0f) - sy, (by0 + 4.0f) - sy, (by0 + 7.0f) - sy};
     const float tb = 2.0f * b;
     const float mbc = -b * __builtin_amdgcn_rcpf(c), mba = -b * __builtin_amdgcn_rcpf(a);
-    float qv[4][2], qh[4][2];  // [edge][range of the other coordinate]
+    const float inf = __builtin_huge_valf();
+    bool inx[2], iny[2];
+    float v[2][2], h[2][2];  // [column][row] minima over the facing vertical / horizontal edge
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float x = ex[i], ax2 = a * x * x, tbx = tb * x, y0 = mbc * x;
-        const float y = ey[i], cy2 = c * y * y, tby = tb * y, x0 = mba * y;
+    for (int k = 0; k < 2; k++) {
+        inx[k] = X[2 * k] <= 0.0f && X[2 * k + 1] >= 0.0f;
+        const float x = X[2 * k] > 0.0f ? X[2 * k] : X[2 * k + 1];
+        const float ax2 = a * x * x, tbx = tb * x, yu = mbc * x;
+        iny[k] = Y[2 * k] <= 0.0f && Y[2 * k + 1] >= 0.0f;
+        const float y = Y[2 * k] > 0.0f ? Y[2 * k] : Y[2 * k + 1];
+        const float cy2 = c * y * y, tby = tb * y, xu = mba * y;
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const float ys = fminf(fmaxf(y0, ey[2 * k]), ey[2 * k + 1]);
-            qv[i][k] = ax2 + tbx * ys + c * ys * ys;
-            const float xs = fminf(fmaxf(x0, ex[2 * k]), ex[2 * k + 1]);
-            qh[i][k] = cy2 + tby * xs + a * xs * xs;
+        for (int j = 0; j < 2; j++) {
+            const float ys = fminf(fmaxf(yu, Y[2 * j]), Y[2 * j + 1]);
+            v[k][j] = inx[k] ? inf : ax2 + tbx * ys + c * ys * ys;
+            const float xs = fminf(fmaxf(xu, X[2 * j]), X[2 * j + 1]);
+            h[j][k] = iny[k] ? inf : cy2 + tby * xs + a * xs * xs;
         }
     }
-    const float mx = fmaxf(fabsf(ex[0]), fabsf(ex[3])), my = fmaxf(fabsf(ey[0]), fabsf(ey[3]));
+    const float mx = fmaxf(fabsf(X[0]), fabsf(X[3])), my = fmaxf(fabsf(Y[0]), fabsf(Y[3]));
     const float bound = 2.0f * (tau + 0.01f + 1e-5f * (a * mx * mx + fabsf(tb) * mx * my + c * my * my));
     unsigned bits = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int kx = k & 1, ky = k >> 1;
-        const bool inside = ex[2 * kx] <= 0.0f && ex[2 * kx + 1] >= 0.0f && ey[2 * ky] <= 0.0f && ey[2 * ky + 1] >= 0.0f;
-        const float qmin = fminf(fminf(qv[2 * kx][ky], qv[2 * kx + 1][ky]), fminf(qh[2 * ky][kx], qh[2 * ky + 1][kx]));
-        if (inside || qmin <= bound) bits |= 1u << k;
+        if ((inx[kx] && iny[ky]) || fminf(v[kx][ky], h[kx][ky]) <= bound) bits |= 1u << k;
     }
     return bits;
 }

@@ -46,50 +46,6 @@ __device__ __forceinline__ V fwd_lds_read(uint32_t at)
 }
 
 
-// The exact test of render_common.h for the four 4x4 quadrants of a block (corner pixel (bx0, by0); bit k of the
-// result is quadrant (k & 1, k >> 1)), from the edges that FACE the splat's centre only: the form is convex with its
-// minimum at the centre, so from the point of a rectangle where it is smallest the way to the centre leaves the
-// rectangle at once -- that point lies on an edge whose outward side the centre is on.  Per axis a quadrant has at
-// most one such edge (none when the centre lies within the quadrant's extent along that axis), and the quadrants of
-// a column (row) share it: four edge lines, each against two extents, instead of eight.  Same threshold and margin.
-__device__ __forceinline__ unsigned fwd_reaches_quadrants(float sx, float sy, float a, float b, float c, float tau,
-                                                          float bx0, float by0)
-{
-    if (!(a > 0.0f && c > 0.0f && a * c - b * b > 0.0f)) return 0xfu;
-    const float X[4] = {bx0 - sx, (bx0 + 3.0f) - sx, (bx0 + 4.0f) - sx, (bx0 + 7.0f) - sx};
-    const float Y[4] = {by0 - sy, (by0 + 3.0f) - sy, (by0 + 4.0f) - sy, (by0 + 7.0f) - sy};
-    const float tb = 2.0f * b;
-    const float mbc = -b * __builtin_amdgcn_rcpf(c), mba = -b * __builtin_amdgcn_rcpf(a);
-    const float inf = __builtin_huge_valf();
-    bool inx[2], iny[2];
-    float v[2][2], h[2][2];  // [column][row] minima over the facing vertical / horizontal edge
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        inx[k] = X[2 * k] <= 0.0f && X[2 * k + 1] >= 0.0f;
-        const float x = X[2 * k] > 0.0f ? X[2 * k] : X[2 * k + 1];
-        const float ax2 = a * x * x, tbx = tb * x, yu = mbc * x;
-        iny[k] = Y[2 * k] <= 0.0f && Y[2 * k + 1] >= 0.0f;
-        const float y = Y[2 * k] > 0.0f ? Y[2 * k] : Y[2 * k + 1];
-        const float cy2 = c * y * y, tby = tb * y, xu = mba * y;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const float ys = fminf(fmaxf(yu, Y[2 * j]), Y[2 * j + 1]);
-            v[k][j] = inx[k] ? inf : ax2 + tbx * ys + c * ys * ys;
-            const float xs = fminf(fmaxf(xu, X[2 * j]), X[2 * j + 1]);
-            h[j][k] = iny[k] ? inf : cy2 + tby * xs + a * xs * xs;
-        }
-    }
-    const float mx = fmaxf(fabsf(X[0]), fabsf(X[3])), my = fmaxf(fabsf(Y[0]), fabsf(Y[3]));
-    const float bound = 2.0f * (tau + 0.01f + 1e-5f * (a * mx * mx + fabsf(tb) * mx * my + c * my * my));
-    unsigned bits = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int kx = k & 1, ky = k >> 1;
-        if ((inx[kx] && iny[ky]) || fminf(v[kx][ky], h[kx][ky]) <= bound) bits |= 1u << k;
-    }
-    return bits;
-}
-
 #ifdef NGS_FWD_STATS
 // Diagnostic build: [0] wave-batches read, [1] survivors of the first test, [2] walks, [3] survivors with a quadrant
 // to visit, [4] list entries (row-visits with an entry), [5] wave-steps (visits of a wave, whatever its rows hold),
@@ -200,7 +156,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, NGS_FWD_WG_PER_CU) void render_fwd_ke
         unsigned bits = 0;
         if (lane < count) {
             const float4 p = rec[lane][0], q = rec[lane][1], c = rec[lane][2];
-            bits = fwd_reaches_quadrants(p.x, p.y, p.z, q.x, p.w, c.z, sx0, sy0);
+            bits = splat_reaches_quadrants(p.x, p.y, p.z, q.x, p.w, c.z, sx0, sy0);
         }
         // a quadrant whose pixels are all saturated (or outside the image) takes no list
         const unsigned long long open = wave_mask(!done);
