@@ -1,10 +1,27 @@
 """Shared helpers for the parity tests: scene/camera cases and state-buffer decoding."""
 import math
+import random
+import socket
 
 import torch
 
 from neuralgaussiansplatting_amd import synthetic
 from neuralgaussiansplatting_amd.cameras import make_camera
+
+
+def free_port():
+    """A TCP port on 127.0.0.1 that nothing listens on and that lies below the range the kernel hands out to outgoing
+    connections (a fixed number up there is now and then taken by some earlier test's connection)."""
+    rng = random.Random()
+    for _ in range(200):
+        port = rng.randrange(12000, 30000)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    raise RuntimeError("no free port found")
 
 
 def case(P, W, H, D, M=None, log_scale=(-3.0, -2.0), seed=1234, eye=(0.7, 0.5, -4.0), bg=(0.0, 0.0, 0.0),

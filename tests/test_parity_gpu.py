@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import case, decode_state, oracle_backward, oracle_forward
+from helpers import case, decode_state, free_port, oracle_backward, oracle_forward
 
 pytestmark = pytest.mark.gpu
 
@@ -1136,7 +1136,7 @@ def test_factored_exchange_over_rccl_single_rank(dgr):
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_rccl_single_rank_worker, args=(33500 + os.getpid() % 2000, ret), nprocs=1, join=True)
+    mp.spawn(_rccl_single_rank_worker, args=(free_port(), ret), nprocs=1, join=True)
     assert dict(ret) == {0: True, 1: []}
 
 

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import free_port
 from neuralgaussiansplatting_amd import loss_utils, synthetic, train_step
 from neuralgaussiansplatting_amd.cameras import make_camera
 
@@ -310,7 +311,7 @@ def test_two_rank_training_keeps_replicas_identical(exchange, views, C):
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 35500 + os.getpid() % 2000 + (7 if exchange == "dense" else 0) + 13 * views
+    port = free_port()
     mp.spawn(_two_rank_trainer_worker, args=(port, exchange, views, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
 
@@ -605,7 +606,7 @@ def test_two_rank_densification_keeps_replicas_identical(C):
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 37700 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_two_rank_densify_worker, args=(port, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
 

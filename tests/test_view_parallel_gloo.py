@@ -5,6 +5,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from helpers import free_port
 from neuralgaussiansplatting_amd import view_parallel
 
 
@@ -274,7 +275,7 @@ def _densify_worker(rank, world, port, ret):
 def test_densification_stats_merge_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_densify_worker, args=(2, 33700 + (os.getpid() % 2000), ret), nprocs=2, join=True)
+    mp.spawn(_densify_worker, args=(2, free_port(), ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
     # without a process group it is a no-op
     a, d, r = torch.ones(3, 1), torch.ones(3, 1), torch.ones(3, dtype=torch.int32)
@@ -286,7 +287,7 @@ def test_factored_exchange_world2():
     world, P, M, D = 2, 41, 16, 3
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 31500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_factored_worker, args=(world, port, P, M, D, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
@@ -295,7 +296,7 @@ def test_two_views_per_rank_with_statistics_world2():
     world, P, M, D, V = 2, 29, 16, 3, 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 27500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_multi_view_worker, args=(world, port, P, M, D, V, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
@@ -307,7 +308,7 @@ def test_chunked_layout_and_view_order_world8():
     for V, chunks in ((1, 3), (2, 3)):
         mgr = mp.Manager()
         ret = mgr.dict()
-        port = 25500 + (os.getpid() % 2000) + V
+        port = free_port()
         mp.spawn(_world8_worker, args=(world, port, P, M, D, V, chunks, ret), nprocs=world, join=True)
         assert dict(ret) == {r: True for r in range(world)}
 
@@ -330,7 +331,7 @@ def test_bucket_all_reduce_world2():
     world, P, M = 2, 37, 16
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_worker, args=(world, port, P, M, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
