@@ -532,7 +532,8 @@ static int forward_impl(const char* fn, ngs_alloc_fn geometry_alloc, void* geome
         }
         ngs_launch_render_fwd(st, cam, ranges, vals[0], rec, background, (float*)(ib + il.final_T),
                               (uint32_t*)(ib + il.n_contrib), out_color, (float*)(gb + gl.acc), P, misc,
-                              pend ? mb->dev + 1 : nullptr, pend ? pend->seq : 0u);
+                              pend ? mb->dev + 1 : nullptr, pend ? pend->seq : 0u, (uint8_t*)(bb + bl.quad),
+                              (uint32_t)(bl.quad / NGS_ALIGN));
         prof_end(ps, ST_RENDER_FWD, st);
         NGS_STAGE("render");
         if (count_known) break;

@@ -26,6 +26,8 @@
 #define NGS_MISC_DMAX 3       // upper bound
 #define NGS_MISC_ACC_CLEAN 4  // 1: the gradient accumulator rows are all zero (the forward pass left them so)
 #define NGS_MISC_T_SCAN 5     // low 32 bits of the device's constant-rate clock when the scan kernel finished
+#define NGS_MISC_QUAD 6       // where BinLayout::quad lies behind the point list, in units of NGS_ALIGN bytes (the
+                              // backward pass is told the instance count, not the capacity the buffer was laid out for)
 // Slots of one accumulator row filled by the backward compositing kernel, summed over the pixels a Gaussian was
 // blended at (d = Gaussian centre - pixel, G = exp(power), o = opacity): DX, DY = sum of o dL/dalpha G d;
 // CON_A, CON_B, CON_C = sum of o dL/dalpha G (dx^2, dx dy, dy^2); OPAC = sum of dL/dalpha G = dL/dopacity;
@@ -90,6 +92,9 @@ struct BinLayout {
                      // per-tile sort)
     size_t hist;     // u32[256 * ngs_sort_blocks(C)] digit-major per-block histogram
     size_t totals;   // u32[256] per-digit totals
+    size_t quad;     // u8[C][4] per instance and 8x8 block of its tile (byte k: block k of the tile, in wave order): bit q
+                     // set when the splat can reach 4x4 quadrant q of the block.  Written by the forward compositing
+                     // kernel for every instance it looks at, read by the backward one instead of repeating the tests.
     size_t total;
 };
 
@@ -209,6 +214,7 @@ static inline BinLayout ngs_bin_layout(size_t C)
     l.keys[1] = o; o = ngs_align_up(o + C * 4);
     l.hist = o; o = ngs_align_up(o + nb * 256 * 4);
     l.totals = o; o = ngs_align_up(o + 256 * 4);
+    l.quad = o; o = ngs_align_up(o + C * 4);
     l.total = o + NGS_ALIGN;
     return l;
 }
@@ -348,16 +354,19 @@ void ngs_launch_sort_segments(hipStream_t s, int T, const uint2* ranges, const f
 // render_fwd.hip
 // acc / P / misc: the compositing kernel also clears the P gradient accumulator rows for the backward pass (it is
 // bound by arithmetic and leaves the memory system idle) and says so in misc[NGS_MISC_ACC_CLEAN].
+// quad / quad_offset: BinLayout::quad of the buffer plist lies in (plist at its start), and its distance from plist in
+// units of NGS_ALIGN bytes, which the kernel leaves in misc[NGS_MISC_QUAD] for the backward pass.
 // stage_clock (or NULL): a word of host memory that receives (seq << 32) | ticks of the device's constant-rate clock
 // that passed between the end of the scan kernel and the start of this kernel, i.e. the duration of the binning stages.
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,
                            uint32_t* n_contrib, float* out_color, float* acc, int P, uint32_t* misc,
-                           unsigned long long* stage_clock, uint32_t seq);
+                           unsigned long long* stage_clock, uint32_t seq, uint8_t* quad, uint32_t quad_offset);
 // render_bwd.hip
 // Clears the accumulator rows unless misc[NGS_MISC_ACC_CLEAN] says they are clear already.
 void ngs_launch_zero_acc_unless_clean(hipStream_t s, float* acc, int P, const uint32_t* misc);
-// misc: the kernel marks the accumulator rows as used (misc[NGS_MISC_ACC_CLEAN] = 0).
+// misc: the kernel marks the accumulator rows as used (misc[NGS_MISC_ACC_CLEAN] = 0) and finds the forward pass's
+// per-quadrant reach bits through misc[NGS_MISC_QUAD], behind plist.
 void ngs_launch_render_bwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, const float* final_T,
                            const uint32_t* n_contrib, const float* dL_dpix, float* acc, uint32_t* misc);

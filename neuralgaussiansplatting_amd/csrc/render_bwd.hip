@@ -76,7 +76,8 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
     const float* __restrict__ dL_dpix, float* __restrict__ acc, uint32_t* __restrict__ misc)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) misc[NGS_MISC_ACC_CLEAN] = 0u;  // the rows are about to be used
-    // record k: [0] = {x, y, conic a, c}, [1] = {conic b, opacity, ln(255 opacity), -}, [2] = {r, g, b, Gaussian id bits}
+    // record k: [0] = {x, y, conic a, c}, [1] = {conic b, opacity, -, the forward pass's reach bits of the instance},
+    // [2] = {r, g, b, Gaussian id bits}
     __shared__ float4 s_rec[BWD_BATCH][3];
     // One table of sums per wave: a wave's LDS operations complete in order, so it adds to its own table with a plain
     // read, add and write.  An LDS float atomic costs about three cycles of the CU's LDS per active lane, ten times
@@ -92,9 +93,6 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
     const int px = tx * NGS_TILE_W + tile_local_x(tid), py = ty * NGS_TILE_H + tile_local_y(tid);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    // corner pixel of this wave's 8x8 block; quadrant k spans [bx0 + 4 (k & 1), +3] x [by0 + 4 (k >> 1), +3]
-    const float bx0 = (float)(tx * NGS_TILE_W + (wave & 1) * NGS_WAVE_W);
-    const float by0 = (float)(ty * NGS_TILE_H + (wave >> 1) * NGS_WAVE_H);
     const uint2 range = ranges[tile];
 
     const size_t tp = (size_t)tile * NGS_TILE_PIX + tid;
@@ -151,22 +149,30 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
 #endif
     // the list entry a thread stages next: fetched a round ahead, so that a round's staging is one dependent memory
     // round trip (the records) instead of two
-    uint32_t next_id = 0;
-    if (tid < BWD_BATCH && (int)tmax - 1 - tid >= 0) next_id = plist[range.x + (uint32_t)((int)tmax - 1 - tid)];
+    // which quadrants of which block each instance can reach, as the forward pass found it: one byte per 8x8 block
+    const uint32_t* const quad = (const uint32_t*)((const char*)plist + (size_t)misc[NGS_MISC_QUAD] * NGS_ALIGN);
+    uint32_t next_id = 0, next_quad = 0;
+    if (tid < BWD_BATCH && (int)tmax - 1 - tid >= 0) {
+        next_id = plist[range.x + (uint32_t)((int)tmax - 1 - tid)];
+        next_quad = quad[range.x + (uint32_t)((int)tmax - 1 - tid)];
+    }
     for (int r = 0; r < rounds; r++) {
         __syncthreads();  // previous batch fully flushed before its LDS is reused
         const int first = (int)tmax - 1 - r * BWD_BATCH;  // list position of slot 0
         const int nb = min(BWD_BATCH, first + 1);
         if (tid < nb) {
-            const uint32_t id = next_id;
-            if (first - BWD_BATCH - tid >= 0) next_id = plist[range.x + (uint32_t)(first - BWD_BATCH - tid)];
+            const uint32_t id = next_id, reach_bits = next_quad;
+            if (first - BWD_BATCH - tid >= 0) {
+                next_id = plist[range.x + (uint32_t)(first - BWD_BATCH - tid)];
+                next_quad = quad[range.x + (uint32_t)(first - BWD_BATCH - tid)];
+            }
             const float4* gr = splat_rec + 4 * (size_t)id;  // one 64-byte line per splat
             const float4 a = gr[0];
             const float4 b = gr[1];
-            const float4 c = gr[2];  // {blue, ln(255 opacity), -, -}
+            const float c = gr[2].x;
             s_rec[tid][0] = make_float4(a.x, a.y, a.z, b.x);
-            s_rec[tid][1] = make_float4(a.w, b.y, c.y, 0.0f);
-            s_rec[tid][2] = make_float4(b.z, b.w, c.x, __uint_as_float(id));
+            s_rec[tid][1] = make_float4(a.w, b.y, 0.0f, __uint_as_float(reach_bits));
+            s_rec[tid][2] = make_float4(b.z, b.w, c, __uint_as_float(id));
         }
         static_assert(sizeof(s_acc) % sizeof(float4) == 0, "the tables are cleared with 16-byte stores");
 #pragma unroll
@@ -182,9 +188,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, 6) void render_bwd_kernel(
             bool r0 = false, r1 = false, r2 = false, r3 = false;
             if (mine < nb) {
                 const uint32_t pos = (uint32_t)(first - mine);
-                const float4 p = s_rec[mine][0];
-                const float4 q = s_rec[mine][1];
-                const unsigned bits = splat_reaches_quadrants(p.x, p.y, p.z, q.x, p.w, q.z, bx0, by0);
+                const unsigned bits = __float_as_uint(s_rec[mine][1].w) >> (8 * wave);
                 r0 = pos < qmax0 && (bits & 1u);
                 r1 = pos < qmax1 && (bits & 2u);
                 r2 = pos < qmax2 && (bits & 4u);

@@ -49,7 +49,7 @@ __device__ __forceinline__ V fwd_lds_read(uint32_t at)
 #ifdef NGS_FWD_STATS
 // Diagnostic build: [0] wave-batches read, [1] survivors of the first test, [2] walks, [3] survivors with a quadrant
 // to visit, [4] list entries (row-visits with an entry), [5] wave-steps (visits of a wave, whatever its rows hold),
-// [6] lane-visits that blended, [7] waves.
+// [6] lane-visits that blended, [7] row-visits in which a lane blended.
 __device__ unsigned long long g_fwd_stats[8];
 extern "C" int ngs_debug_fwd_stats(unsigned long long* out)
 {
@@ -69,14 +69,16 @@ __global__ __launch_bounds__(NGS_TILE_PIX, NGS_FWD_WG_PER_CU) void render_fwd_ke
     int W, int H, int grid_x, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
     const float4* __restrict__ rec_g, const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ acc, int acc_f4_per_block, int acc_f4_total,
-    uint32_t* __restrict__ misc, unsigned long long* __restrict__ stage_clock, uint32_t seq)
+    uint32_t* __restrict__ misc, unsigned long long* __restrict__ stage_clock, uint32_t seq,
+    uint8_t* __restrict__ quad, uint32_t quad_offset)
 {
     // per wave, slot k (48 bytes): [0] = {x, y, conic a, c}, [1] = {conic b, opacity, r, g}, [2] = {b, list position + 1,
     // ln(255 opacity), -}; slot FWD_SLOTS is all zeros: a splat of opacity 0, which no pixel blends
     __shared__ float4 s_rec[NGS_TILE_PIX / 64][FWD_SLOTS + 1][3];
     // per wave and quadrant: the LDS addresses of the slots the quadrant has to visit, in list order
     __shared__ uint32_t s_list[NGS_TILE_PIX / 64][4][FWD_SLOTS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, row = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // the same in all lanes: addresses formed from it stay scalar
     const int tile = blockIdx.x;
     // This workgroup's share of the backward pass's accumulator rows is cleared here: the stores leave at once and
     // complete behind the compositing, which keeps the vector ALU busy and the memory system idle.
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, NGS_FWD_WG_PER_CU) void render_fwd_ke
         for (int i = lo + tid; i < hi; i += NGS_TILE_PIX) stream_store4(acc + 4 * (size_t)i, make_float4(0.f, 0.f, 0.f, 0.f));
         if (tile == 0 && tid == 0) {
             misc[NGS_MISC_ACC_CLEAN] = 1u;
+            misc[NGS_MISC_QUAD] = quad_offset;
             // How long the binning stages between the scan and this kernel took, posted to the host, which picks
             // the source of the depth order for later frames by what each one has cost (capi.hip).
             if (stage_clock)
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, NGS_FWD_WG_PER_CU) void render_fwd_ke
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     float4(*rec)[3] = s_rec[wave];
+    uint8_t* const wave_quad = quad + 4 * (size_t)range.x + wave;  // this block's byte of the tile's first instance
     if (lane < 3) rec[FWD_SLOTS][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t my_slot_lds = fwd_lds_address(&rec[lane][0]);
     const uint32_t null_lds = fwd_lds_address(&rec[FWD_SLOTS][0]);
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, NGS_FWD_WG_PER_CU) void render_fwd_ke
     static_assert(sizeof(s_list[0]) == 64 * sizeof(uint4), "a wave clears its four lists with one 16-byte store per lane");
 
 #ifdef NGS_FWD_STATS
-    unsigned long long fst[8] = {0, 0, 0, 0, 0, 0, 0, 1};
+    unsigned long long fst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     bool done = !inside;
     float T = 1.0f, Cb = 0.0f;
@@ -143,6 +147,13 @@ __global__ __launch_bounds__(NGS_TILE_PIX, NGS_FWD_WG_PER_CU) void render_fwd_ke
         // adds (colour * 0) * T, an exact zero, instead of selecting its old value three times.
         FSTAT(5, 1);
         FSTAT(6, __popcll(wave_mask(blend)));
+#ifdef NGS_FWD_STATS
+        {
+            const unsigned long long bm = wave_mask(blend);
+            fst[7] += ((bm & 0xffffull) != 0) + ((bm & 0xffff0000ull) != 0) + ((bm & 0xffff00000000ull) != 0) +
+                      ((bm & 0xffff000000000000ull) != 0);
+        }
+#endif
         const float alpha_b = blend ? alpha : 0.0f;
         const fwd_f2 Tp = {T, T}, ab = {alpha_b, alpha_b};
         Crg = __builtin_elementwise_fma(q.zw * ab, Tp, Crg);
@@ -157,6 +168,10 @@ __global__ __launch_bounds__(NGS_TILE_PIX, NGS_FWD_WG_PER_CU) void render_fwd_ke
         if (lane < count) {
             const float4 p = rec[lane][0], q = rec[lane][1], c = rec[lane][2];
             bits = splat_reaches_quadrants(p.x, p.y, p.z, q.x, p.w, c.z, sx0, sy0);
+            // The backward pass walks the same quadrants' lists: it is handed the bits instead of repeating the
+            // tests.  Every instance the wave looks at gets its byte exactly once, here or where the first test
+            // drops it.
+            wave_quad[4u * (__float_as_uint(c.y) - 1u)] = (uint8_t)bits;
         }
         // a quadrant whose pixels are all saturated (or outside the image) takes no list
         const unsigned long long open = wave_mask(!done);
@@ -220,6 +235,7 @@ __global__ __launch_bounds__(NGS_TILE_PIX, NGS_FWD_WG_PER_CU) void render_fwd_ke
             const float mag = a.z * mx * mx + fabsf(2.0f * a.w) * mx * my + b.x * my * my;
             reach = !(0.5f * lb > c.y + 0.01f + 1e-5f * mag);
         }
+        if (have && !reach) wave_quad[4u * (uint32_t)(base + lane)] = 0;
         const unsigned long long mask = wave_mask(reach);
         const int cnt = __popcll(mask);
         FSTAT(0, base < n ? 1 : 0);
@@ -262,10 +278,11 @@ __global__ __launch_bounds__(NGS_TILE_PIX, NGS_FWD_WG_PER_CU) void render_fwd_ke
 void ngs_launch_render_fwd(hipStream_t s, const NgsCamera& cam, const uint2* ranges, const uint32_t* plist,
                            const float4* rec, const float* bg, float* final_T,
                            uint32_t* n_contrib, float* out_color, float* acc, int P, uint32_t* misc,
-                           unsigned long long* stage_clock, uint32_t seq)
+                           unsigned long long* stage_clock, uint32_t seq, uint8_t* quad, uint32_t quad_offset)
 {
     const int T = cam.grid_x * cam.grid_y;
     const long long f4 = (long long)P * (NGS_ACC_STRIDE / 4);  // P <= NGS_MAX_GAUSSIANS keeps this inside an int
     hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(NGS_TILE_PIX), 0, s, cam.W, cam.H, cam.grid_x, ranges, plist,
-                       rec, bg, final_T, n_contrib, out_color, acc, (int)((f4 + T - 1) / T), (int)f4, misc, stage_clock, seq);
+                       rec, bg, final_T, n_contrib, out_color, acc, (int)((f4 + T - 1) / T), (int)f4, misc, stage_clock, seq, quad,
+                       quad_offset);
 }
