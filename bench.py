@@ -51,7 +51,7 @@ def stage_bytes(P, R, W, H, D, M, vis, views=1):
     tile_passes = (T.bit_length() + 7) // 8  # bit_length(T) is the reference's getHigherMsb(T)
     vP = vis * P
     return {
-        "preprocess_fwd": P * (12 + 8) + vP * (32 + 12 * c + 49),
+        "preprocess_fwd": P * (12 + 8) + vP * (32 + 12 * c + 61),
         "scan_block_sums": 8 * ((P + 255) // 256),
         # the tile-level sort moves (tile id, Gaussian index) pairs of 8 bytes; the depth joins in the per-tile sort
         # tile count; rectangle, offset share and depth; key + list word; the tile ranges zeroed on the side
