@@ -86,9 +86,11 @@ int ngs_rasterize_forward_presized(ngs_alloc_fn geometry_alloc, void* geometry_c
 /*
  * Rasterizer::backward (rasterizer.h:55-84, rasterizer_impl.cu:340-434).
  * geom_buffer / binning_buffer / image_buffer are the buffers the forward call
- * filled (or copies of them at addresses with the same residue modulo 256;
- * they are re-carved from P and the image size; of the binning buffer only the
- * first 4 * R bytes past the 256-byte boundary, the sorted point list, are read).  Every output element is WRITTEN (zeros for culled Gaussians), so
+ * filled (or whole copies of them at addresses with the same residue modulo 256;
+ * they are re-carved from P and the image size; of the binning buffer the
+ * first 4 * R bytes past the 256-byte boundary, the sorted point list, are read, and the forward compositing
+ * kernel's per-quadrant reach bytes, which lie where a word of geom_buffer says: the three buffers must be those
+ * of one forward call).  Every output element is WRITTEN (zeros for culled Gaussians), so
  * the caller need not zero-fill; dL_dconic ([P][2][2]) may be NULL, and so may dL_dsh (the SH coefficient gradient
  * is then not produced; its share of dL_dmean3D still is -- see ngs_sh_gradient_from_views).
  * rotations, dL_drot and dL_dconic must be 16-byte aligned (an error otherwise); D and M as in the forward call.
