@@ -2,7 +2,9 @@
 // (every 16-lane row has its own list of the 64-splat batch's survivors).  Bit-identical images and contributor
 // counts, 0.366 ms at 3 M Gaussians / 1080p against 0.364 for the block-wide walk with two splats per trip: with 64
 // splats per batch a row walks about a dozen entries per batch, and building four lists per batch costs what the
-// shorter walk saves.  To try it: copy over csrc/render_fwd.hip and rebuild.
+// shorter walk saves.  (A record of that experiment: it is written against the library's headers and launch signature
+// as they were then.  The library's kernel now walks per quadrant too, after parking survivors across batches and
+// classifying 64 of them at a time, which is what makes the four lists pay -- see csrc/render_fwd.hip.)
 // Per-tile front-to-back alpha compositing (forward).  One 256-thread
 // workgroup per 16x16 tile, four wave64s each covering a 8x8 pixel block.
 //
